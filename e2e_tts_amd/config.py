@@ -1,0 +1,304 @@
+"""Configuration for the hot path.
+
+The reference merges three YAML files into ``{"audio", "models", "train"}``
+(reference: e2e_tts/src/tools/tools_for_model.py:14-20) and stores the result
+as ``config.yaml`` next to the acoustic checkpoint, where ``TTS.__init__``
+reads it back (reference: e2e_tts/src/api/utils.py:34-36).  This module holds
+
+* ``default_config()`` -- the same dictionary *shape* with the hot-path keys
+  only (values: reference e2e_tts/config/model_config.yaml:1-92 and
+  e2e_tts/config/preprocessing_config.yaml:1-14), used for synthetic weights;
+* ``EngineDims`` -- the flat, integer view of that dictionary that crosses the
+  C ABI as ``e2etts_config`` (include/e2etts.h).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes
+from dataclasses import dataclass, field
+from typing import List
+
+N_SYMBOLS = 131  # reference: e2e_tts/models/g2p/symbols.py:19-50
+
+_DEFAULT = {
+    "audio": {
+        "signal": {"sampling_rate": 22050, "max_wav_value": 32768.0},
+        "stft": {"filter_length": 1024, "hop_length": 256, "win_length": 1024},
+        "mel": {"channels": 80},
+    },
+    "models": {
+        "fastspeech2": {
+            "max_seq_len": 1000,
+            "encoder_layers": 6,
+            "encoder_hidden": 384,
+            "decoder_layers": 6,
+            "decoder_hidden": 384,
+            "building_block": {
+                "block_type": "transformer",
+                "transformer": {
+                    "encoder_head": 2,
+                    "decoder_head": 2,
+                    "conv_filter_size": 1024,
+                    "conv_kernel_size": [9, 1],
+                    "encoder_dropout": 0.1,
+                    "decoder_dropout": 0.1,
+                },
+            },
+            "variance": {
+                "duration_modelling": {
+                    "learn_alignment": True,
+                    "aligner_temperature": 0.0005,
+                    "binarization_start_steps": 6000,
+                },
+                "variance_predictor": {
+                    "predictor_grad": 0.1,
+                    "filter_size": 256,
+                    "kernel_size": 3,
+                    "dropout": 0.5,
+                    "dur_predictor_layers": 2,
+                    "dur_predictor_kernel": 3,
+                    "pit_predictor_layers": 2,
+                    "pit_predictor_kernel": 5,
+                    "ener_predictor_layers": 2,
+                    "ener_predictor_kernel": 5,
+                    "ffn_padding": "SAME",
+                    "ffn_act": "gelu",
+                },
+                "variance_embedding": {
+                    "use_uv": True,
+                    "n_bins": 256,
+                    "pitch_feature": "phoneme_level",
+                    "pitch_quantization": "linear",
+                    "energy_feature": "phoneme_level",
+                    "energy_quantization": "linear",
+                    "f0_bins": 300,
+                },
+            },
+            "postnet": {"embedding_dim": 512, "conv_layers": 5, "kernel_size": 5},
+        },
+        "hifigan": {
+            "resblock": 1,
+            "upsample_rates": [8, 8, 2, 2],
+            "upsample_kernel_sizes": [16, 16, 4, 4],
+            "upsample_initial_channel": 512,
+            "resblock_kernel_sizes": [3, 7, 11],
+            "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+        },
+    },
+}
+
+#: stats.json of the synthetic model; the reference reads
+#: these keys at U/layers.py:77-84,115-122,152.
+DEFAULT_STATS = {
+    "f0": {"mean": 191.463, "std": 67.695},
+    "pitch": {"min": -2.047, "max": 10.332},
+    "energy": {"min": -1.258, "max": 7.351},
+}
+
+DEFAULT_SPEAKERS = {"hn_minhphuong": 0, "spk_b": 1, "spk_c": 2, "spk_d": 3}
+
+
+def default_config() -> dict:
+    return copy.deepcopy(_DEFAULT)
+
+
+def tiny_config() -> dict:
+    """A small model (hidden 64, 2+2 layers, vocoder width 64) for fast tests.
+
+    Every structural feature of the default model is kept (2 heads, k9/k1 FFN,
+    k3/k5 predictors, 5-layer postnet, 4 upsampling stages x 3 ResBlock1).
+    """
+    c = default_config()
+    fs = c["models"]["fastspeech2"]
+    fs["max_seq_len"] = 60
+    fs["encoder_layers"] = 2
+    fs["decoder_layers"] = 2
+    fs["encoder_hidden"] = 64
+    fs["decoder_hidden"] = 64
+    fs["building_block"]["transformer"]["conv_filter_size"] = 96
+    fs["variance"]["variance_predictor"]["filter_size"] = 48
+    fs["postnet"]["embedding_dim"] = 48
+    c["models"]["hifigan"]["upsample_initial_channel"] = 64
+    return c
+
+
+MAX_STAGES = 8
+MAX_RESBLOCK_KERNELS = 4
+MAX_DILATIONS = 4
+
+
+class CEngineConfig(ctypes.Structure):
+    """Mirror of ``e2etts_config`` in include/e2etts.h (keep in sync)."""
+
+    _fields_ = [
+        ("n_symbols", ctypes.c_int32),
+        ("n_speakers", ctypes.c_int32),
+        ("n_mel", ctypes.c_int32),
+        ("hidden", ctypes.c_int32),
+        ("enc_layers", ctypes.c_int32),
+        ("dec_layers", ctypes.c_int32),
+        ("n_head", ctypes.c_int32),
+        ("ffn_dim", ctypes.c_int32),
+        ("ffn_k1", ctypes.c_int32),
+        ("ffn_k2", ctypes.c_int32),
+        ("max_seq_len", ctypes.c_int32),
+        ("dur_layers", ctypes.c_int32),
+        ("dur_kernel", ctypes.c_int32),
+        ("dur_chans", ctypes.c_int32),
+        ("var_layers", ctypes.c_int32),
+        ("var_kernel", ctypes.c_int32),
+        ("var_chans", ctypes.c_int32),
+        ("n_bins", ctypes.c_int32),
+        ("postnet_layers", ctypes.c_int32),
+        ("postnet_dim", ctypes.c_int32),
+        ("postnet_kernel", ctypes.c_int32),
+        ("voc_init_ch", ctypes.c_int32),
+        ("voc_stages", ctypes.c_int32),
+        ("voc_up_rate", ctypes.c_int32 * MAX_STAGES),
+        ("voc_up_kernel", ctypes.c_int32 * MAX_STAGES),
+        ("voc_n_kernels", ctypes.c_int32),
+        ("voc_rb_kernel", ctypes.c_int32 * MAX_RESBLOCK_KERNELS),
+        ("voc_n_dil", ctypes.c_int32),
+        ("voc_rb_dil", (ctypes.c_int32 * MAX_DILATIONS) * MAX_RESBLOCK_KERNELS),
+        ("hop_length", ctypes.c_int32),
+        ("sample_rate", ctypes.c_int32),
+        ("pos_table_rows", ctypes.c_int32),
+        ("f0_mean", ctypes.c_float),
+        ("f0_std", ctypes.c_float),
+    ]
+
+
+@dataclass
+class EngineDims:
+    n_symbols: int
+    n_speakers: int
+    n_mel: int
+    hidden: int
+    enc_layers: int
+    dec_layers: int
+    n_head: int
+    ffn_dim: int
+    ffn_k1: int
+    ffn_k2: int
+    max_seq_len: int
+    dur_layers: int
+    dur_kernel: int
+    dur_chans: int
+    var_layers: int
+    var_kernel: int
+    var_chans: int
+    n_bins: int
+    postnet_layers: int
+    postnet_dim: int
+    postnet_kernel: int
+    voc_init_ch: int
+    voc_up_rate: List[int] = field(default_factory=list)
+    voc_up_kernel: List[int] = field(default_factory=list)
+    voc_rb_kernel: List[int] = field(default_factory=list)
+    voc_rb_dil: List[List[int]] = field(default_factory=list)
+    hop_length: int = 256
+    sample_rate: int = 22050
+    pos_table_rows: int = 4096
+    f0_mean: float = 0.0
+    f0_std: float = 1.0
+
+    @property
+    def upsample_total(self) -> int:
+        t = 1
+        for r in self.voc_up_rate:
+            t *= r
+        return t
+
+    def to_c(self) -> CEngineConfig:
+        c = CEngineConfig()
+        for name in (
+            "n_symbols n_speakers n_mel hidden enc_layers dec_layers n_head ffn_dim ffn_k1 ffn_k2 "
+            "max_seq_len dur_layers dur_kernel dur_chans var_layers var_kernel var_chans n_bins "
+            "postnet_layers postnet_dim postnet_kernel voc_init_ch hop_length sample_rate pos_table_rows"
+        ).split():
+            setattr(c, name, int(getattr(self, name)))
+        c.f0_mean = float(self.f0_mean)
+        c.f0_std = float(self.f0_std)
+        if len(self.voc_up_rate) > MAX_STAGES or len(self.voc_rb_kernel) > MAX_RESBLOCK_KERNELS:
+            raise ValueError("vocoder config exceeds the C-ABI limits")
+        c.voc_stages = len(self.voc_up_rate)
+        for i, (r, k) in enumerate(zip(self.voc_up_rate, self.voc_up_kernel)):
+            c.voc_up_rate[i] = r
+            c.voc_up_kernel[i] = k
+        c.voc_n_kernels = len(self.voc_rb_kernel)
+        c.voc_n_dil = len(self.voc_rb_dil[0])
+        for j, k in enumerate(self.voc_rb_kernel):
+            c.voc_rb_kernel[j] = k
+            if len(self.voc_rb_dil[j]) != c.voc_n_dil or c.voc_n_dil > MAX_DILATIONS:
+                raise ValueError("ragged / oversize resblock dilation list")
+            for m, d in enumerate(self.voc_rb_dil[j]):
+                c.voc_rb_dil[j][m] = d
+        return c
+
+
+def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int = N_SYMBOLS,
+                     pos_table_rows: int = 4096) -> EngineDims:
+    """Flatten the reference-style config dict into the engine dims.
+
+    Raises for every configuration the hot path does not implement, naming the
+    reference location that selects it, instead of silently computing
+    something else.
+    """
+    fs = config["models"]["fastspeech2"]
+    hg = config["models"]["hifigan"]
+    bt = fs["building_block"]["block_type"]
+    if bt != "transformer":
+        raise NotImplementedError(
+            f"building_block.block_type={bt!r}: only the default 'transformer' FFT block is on the hot path "
+            "(reference U/model.py:24-33; SURVEY.md section 8(f))")
+    tr = fs["building_block"]["transformer"]
+    if tr["encoder_head"] != tr["decoder_head"]:
+        raise NotImplementedError("encoder_head != decoder_head")
+    if fs["encoder_hidden"] != fs["decoder_hidden"]:
+        raise NotImplementedError("encoder_hidden != decoder_hidden")
+    var = fs["variance"]
+    if not var["duration_modelling"]["learn_alignment"]:
+        raise NotImplementedError("SupervisedFastSpeech2 is out of scope (reference API/utils.py:37-40)")
+    ve = var["variance_embedding"]
+    if not ve["use_uv"] or ve["pitch_feature"] != "phoneme_level" or ve["energy_feature"] != "phoneme_level":
+        raise NotImplementedError("only use_uv=True, phoneme-level pitch/energy are implemented (reference U/layers.py:136-173)")
+    if ve["pitch_quantization"] != "linear":
+        raise NotImplementedError("pitch_quantization must be 'linear' (reference U/layers.py:151-152)")
+    vp = var["variance_predictor"]
+    if vp["ffn_padding"] != "SAME":
+        raise NotImplementedError("ffn_padding must be 'SAME'")
+    if vp["pit_predictor_layers"] != vp["ener_predictor_layers"] or vp["pit_predictor_kernel"] != vp["ener_predictor_kernel"]:
+        raise NotImplementedError("pitch and energy predictors must share depth/kernel")
+    if hg["resblock"] != 1:
+        raise NotImplementedError("only ResBlock1 (HiFi-GAN V1) is implemented (reference V/generator.py:19)")
+    for k, u in zip(hg["upsample_kernel_sizes"], hg["upsample_rates"]):
+        if k != 2 * u or u % 2:
+            raise NotImplementedError("upsample kernel must be 2 x rate with even rate (polyphase 3-tap form)")
+    n_mel = config["audio"]["mel"]["channels"]
+    hop = config["audio"]["stft"]["hop_length"]
+    dims = EngineDims(
+        n_symbols=n_symbols, n_speakers=n_speakers, n_mel=n_mel,
+        hidden=fs["encoder_hidden"], enc_layers=fs["encoder_layers"], dec_layers=fs["decoder_layers"],
+        n_head=tr["encoder_head"], ffn_dim=tr["conv_filter_size"],
+        ffn_k1=tr["conv_kernel_size"][0], ffn_k2=tr["conv_kernel_size"][1],
+        max_seq_len=fs["max_seq_len"],
+        dur_layers=vp["dur_predictor_layers"], dur_kernel=vp["dur_predictor_kernel"], dur_chans=n_mel,
+        var_layers=vp["pit_predictor_layers"], var_kernel=vp["pit_predictor_kernel"], var_chans=vp["filter_size"],
+        n_bins=ve["n_bins"],
+        postnet_layers=fs["postnet"]["conv_layers"], postnet_dim=fs["postnet"]["embedding_dim"],
+        postnet_kernel=fs["postnet"]["kernel_size"],
+        voc_init_ch=hg["upsample_initial_channel"],
+        voc_up_rate=list(hg["upsample_rates"]), voc_up_kernel=list(hg["upsample_kernel_sizes"]),
+        voc_rb_kernel=list(hg["resblock_kernel_sizes"]),
+        voc_rb_dil=[list(d) for d in hg["resblock_dilation_sizes"]],
+        hop_length=hop, sample_rate=config["audio"]["signal"]["sampling_rate"],
+        pos_table_rows=pos_table_rows,
+        f0_mean=float(stats["f0"]["mean"]), f0_std=float(stats["f0"]["std"]),
+    )
+    if dims.ffn_k2 != 1:
+        raise NotImplementedError("second FFN conv must be k=1")
+    if dims.upsample_total != hop:
+        raise ValueError(f"product of upsample_rates ({dims.upsample_total}) != hop_length ({hop})")
+    if dims.hidden % dims.n_head:
+        raise ValueError("hidden not divisible by heads")
+    return dims

@@ -1,0 +1,380 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules on CPU.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees
+it).  The reference source is imported from where it lies and never copied:
+fixtures hold inputs and the reference's outputs only.
+
+Recipe: a stand-in ``numba`` module (identity ``jit``,
+``prange = range``) is put on sys.path because U/function.py:2 imports numba for
+two training-only functions; then ``models`` is imported from
+/root/reference/e2e_tts.  Synthetic state dicts come from
+e2e_tts_amd.synth_weights and are loaded with ``strict=True`` -- which proves
+the manifest exact.
+
+The host-loop methods (TTS.arrange_text / input_parse / combine_audio,
+API/utils.py:64-117) live in a module whose import needs ffmpy/pydub/g2p and
+instantiates an uploader; those three pure methods are therefore extracted
+from the reference file with ``ast`` and executed as-is with a toy tokenizer.
+
+Usage:  python oracle/make_goldens.py [--only NAME] [--skip-large]
+"""
+from __future__ import annotations
+
+import argparse
+import ast
+import os
+import sys
+import tempfile
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from e2e_tts_amd import config as cfgmod  # noqa: E402
+from e2e_tts_amd import synth_weights as sw  # noqa: E402
+from oracle import ref_numpy as orc  # noqa: E402
+
+
+def import_reference():
+    tmp = tempfile.mkdtemp(prefix="numba_standin_")
+    os.makedirs(os.path.join(tmp, "numba"))
+    with open(os.path.join(tmp, "numba", "__init__.py"), "w") as f:
+        f.write("def jit(*a, **k):\n"
+                "    if len(a) == 1 and callable(a[0]) and not k: return a[0]\n"
+                "    return lambda f: f\n"
+                "prange = range\n")
+    sys.path.insert(0, tmp)
+    sys.path.insert(0, os.path.join(REF, "e2e_tts"))
+    warnings.filterwarnings("ignore")
+    import models  # noqa
+    return models
+
+
+def build_reference(models, config, stats, n_speakers, ac_state, voc_state):
+    import torch
+    m = models.UnsupervisedFastSpeech2(n_symbols=cfgmod.N_SYMBOLS, n_speakers=n_speakers,
+                                       n_channels=config["audio"]["mel"]["channels"],
+                                       config=config["models"]["fastspeech2"], stats=stats)
+    m.load_state_dict(sw.to_torch(ac_state), strict=True)
+    m.eval()
+    v = models.HifiGan(config["models"]["hifigan"])
+    v.load_state_dict(sw.to_torch(voc_state), strict=True)
+    v.eval()
+    torch.set_grad_enabled(False)
+    return m, v
+
+
+def run_reference(m, v, ids, lens, speaker, controls=(1.0, 1.0, 1.0), run_vocoder=True):
+    """controls = (d, p, e).  Returns dict of numpy outputs incl. hooked intermediates."""
+    import torch
+    trace = {}
+    hooks = []
+    hooks.append(m.encoder.register_forward_hook(lambda mod, i, o: trace.__setitem__("enc_out", o[0].numpy().copy())))
+    hooks.append(m.decoder.register_forward_hook(lambda mod, i, o: trace.__setitem__("dec_out", o[0].numpy().copy())))
+
+    def va_hook(mod, i, o):
+        x, log_d, dur, p_pred, e_pred, mel_lens, mel_mask, _ = o[0]
+        trace.update(lr_out=x.numpy().copy(), log_d=log_d.numpy().copy(), pitch_pred=p_pred.numpy().copy(),
+                     energy_pred=e_pred.numpy().copy())
+    hooks.append(m.variance_adaptor.register_forward_hook(va_hook))
+    hooks.append(m.variance_adaptor.pitch_embedding.register_forward_hook(
+        lambda mod, i, o: trace.__setitem__("pitch_idx", i[0].numpy().copy())))
+    hooks.append(m.variance_adaptor.energy_embedding.register_forward_hook(
+        lambda mod, i, o: trace.__setitem__("energy_idx", i[0].numpy().copy())))
+    t_ids = torch.from_numpy(np.asarray(ids, dtype=np.int64))
+    t_lens = torch.from_numpy(np.asarray(lens, dtype=np.int64))
+    t0 = time.time()
+    (mel, mel_post, dur), mel_lens = m.inference(speaker=torch.tensor([speaker]), texts=t_ids, txt_lens=t_lens,
+                                                 max_txt_len=int(t_ids.shape[1]),
+                                                 d_control=controls[0], p_control=controls[1], e_control=controls[2])
+    t_ac = time.time() - t0
+    for h in hooks:
+        h.remove()
+    out = dict(trace)
+    out.update(mel=mel.numpy(), mel_post=mel_post.numpy(), dur=dur.numpy(), mel_lens=mel_lens.numpy())
+    if run_vocoder:
+        t0 = time.time()
+        wav = v(mel_post.transpose(1, 2)).squeeze(1)
+        out["wav"] = wav.numpy()
+        out["t_vocoder_s"] = time.time() - t0
+    out["t_acoustic_s"] = t_ac
+    return out
+
+
+def margins(out, energy_bins, stats, controls=(1.0, 1.0, 1.0), lens=None):
+    """Distance of every discrete decision to its rounding boundary (fp32 reference values)."""
+    L = out["log_d"].shape[1]
+    valid = np.arange(L)[None, :] < np.asarray(lens)[:, None]
+    d = np.exp(out["log_d"].astype(np.float64)) - 1
+    m_dur = np.abs((d - np.floor(d)) - 0.5)
+    m_dur = np.where(valid, m_dur, 1.0)
+    p = out["pitch_pred"].astype(np.float64)  # already multiplied by p_control (U/layers.py:147)
+    f0 = p[..., 0] * stats["f0"]["std"] + stats["f0"]["mean"]
+    uv = p[..., 1] > 0
+    m_uv = np.abs(p[..., 1])
+    mel = 1127 * np.log(1 + np.maximum(f0, -699.0) / 700)
+    b = np.where(mel > 0, (mel - orc.F0_MEL_MIN) * 254 / (orc.F0_MEL_MAX - orc.F0_MEL_MIN) + 1, mel)
+    # idx = trunc(clip(b, 1, 255) + 0.5) is continuous at both clip points and at mel == 0,
+    # so the only boundaries are the half-integers of b and the uv threshold.
+    fb = np.clip(b, 1, 255) + 0.5
+    m_f0 = np.where(uv, 1.0, np.minimum(fb - np.floor(fb), np.ceil(fb) - fb))
+    m_f0 = np.where(valid, m_f0, 1.0)
+    m_uv = np.where(valid, m_uv, 1.0)
+    e = out["energy_pred"].astype(np.float64) * controls[2]
+    m_en = np.abs(e[..., None] - energy_bins[None, None, :].astype(np.float64)).min(axis=-1)
+    m_en = m_en / float(energy_bins[1] - energy_bins[0])  # in bucket units
+    m_en = np.where(valid, m_en, 1.0)
+    return dict(dur=float(m_dur.min()), uv=float(m_uv.min()), f0=float(m_f0.min()), energy=float(m_en.min()))
+
+
+def oracle_margin(ac_oracle, ids, lens, speaker, stats, controls=(1.0, 1.0, 1.0)):
+    """Cheap margin probe with the numpy oracle's encoder + variance adaptor only (for the seed search)."""
+    ids = np.asarray(ids, np.int64)
+    lens = np.asarray(lens, np.int64)
+    pad = orc.get_mask_from_lengths(lens, ids.shape[1])
+    x = ac_oracle.encoder(ids, pad) + ac_oracle.sd["speaker_emb.weight"][[speaker]][:, None, :]
+    out = dict(log_d=ac_oracle.duration_predictor(x, pad),
+               pitch_pred=ac_oracle.variance_predictor("pitch", x) * np.float32(controls[1]),
+               energy_pred=ac_oracle.variance_predictor("energy", x)[..., 0])
+    return margins(out, ac_oracle.sd["variance_adaptor.energy_bins"], stats, controls, lens)
+
+
+def make_ids(seed, lens, L=None):
+    """ids uniform in [4, 130], pad = 0."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    L = L or int(max(lens))
+    ids = np.zeros((len(lens), L), dtype=np.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(4, 131, size=n)
+    return ids
+
+
+def search_ids(ac_oracle, lens, speaker, stats, controls, want, max_tries, first_seed, fixed_durations):
+    best = None
+    for s in range(first_seed, first_seed + max_tries):
+        ids = make_ids(s, lens)
+        mg = oracle_margin(ac_oracle, ids, lens, speaker, stats, controls)
+        keys = ("uv", "f0", "energy") if fixed_durations else ("dur", "uv", "f0", "energy")
+        worst = min(mg[k] for k in keys)
+        if best is None or worst > best[0]:
+            best = (worst, s, ids, mg)
+        if worst >= want:
+            break
+    print(f"    ids seed {best[1]}: min margin {best[0]:.2e} ({best[3]})", flush=True)
+    return best[1], best[2]
+
+
+def wav_digest(wav, lens_samples):
+    """Strided / cropped view of a waveform batch + float64 checksums (keeps fixtures small)."""
+    d = {}
+    d["wav_stride"] = np.int64(16)
+    d["wav_strided"] = wav[:, ::16].copy()
+    d["wav_head"] = wav[:, :2048].copy()
+    d["wav_sum"] = np.array([wav[b, :n].astype(np.float64).sum() for b, n in enumerate(lens_samples)])
+    d["wav_abs_sum"] = np.array([np.abs(wav[b, :n].astype(np.float64)).sum() for b, n in enumerate(lens_samples)])
+    return d
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
+
+
+# --------------------------------------------------------------------------- cases
+
+def case_model(models, name, config, mode, lens, speaker, controls, ids_seed, want_margin, store, w_seed=(1234, 4321),
+               max_tries=40):
+    print(f"[{name}]", flush=True)
+    stats = cfgmod.DEFAULT_STATS
+    n_spk = 4
+    ac_state = sw.make_acoustic_state(config, stats, n_spk, seed=w_seed[0], mode=mode)
+    voc_state = sw.make_vocoder_state(config, seed=w_seed[1])
+    ac_or = orc.AcousticOracle(ac_state, config, stats)
+    seed, ids = search_ids(ac_or, lens, speaker, stats, controls, want_margin, max_tries, ids_seed, mode == "fixed")
+    m, v = build_reference(models, config, stats, n_spk, ac_state, voc_state)
+    out = run_reference(m, v, ids, lens, speaker, controls)
+    mg = margins(out, ac_state["variance_adaptor.energy_bins"], stats, controls, lens)
+    print(f"    reference margins {mg}; T={out['mel'].shape[1]} acoustic {out['t_acoustic_s']:.2f}s vocoder {out['t_vocoder_s']:.2f}s", flush=True)
+    hop = config["audio"]["stft"]["hop_length"]
+    meta = dict(ids=ids, lens=np.asarray(lens, np.int64), speaker=np.int64(speaker),
+                controls=np.asarray(controls, np.float64), ids_seed=np.int64(seed),
+                weight_seeds=np.asarray(w_seed, np.int64), mode=np.array(mode),
+                margin_dur=mg["dur"], margin_uv=mg["uv"], margin_f0=mg["f0"], margin_energy=mg["energy"],
+                ref_t_acoustic_s=out["t_acoustic_s"], ref_t_vocoder_s=out["t_vocoder_s"])
+    arrays = dict(meta)
+    for k in ("dur", "mel_lens", "pitch_idx", "energy_idx", "log_d", "pitch_pred", "energy_pred"):
+        arrays[k] = out[k]
+    if store == "full":
+        for k in ("enc_out", "lr_out", "dec_out", "mel", "mel_post", "wav"):
+            arrays[k] = out[k]
+    elif store == "medium":
+        arrays["mel_post"] = out["mel_post"]
+        arrays["mel"] = out["mel"]
+        arrays.update(wav_digest(out["wav"], out["mel_lens"] * hop))
+    else:  # "digest": a few utterances, strided frames
+        sel = np.array(sorted({int(np.argmax(lens)), int(np.argmin(lens)), len(lens) // 2}))
+        arrays["sel"] = sel
+        arrays["mel_post_sel"] = out["mel_post"][sel][:, ::4].copy()
+        arrays["mel_frame_stride"] = np.int64(4)
+        arrays["mel_post_sum"] = np.array([out["mel_post"][b, :n].astype(np.float64).sum() for b, n in enumerate(out["mel_lens"])])
+        arrays["mel_post_abs_sum"] = np.array([np.abs(out["mel_post"][b, :n].astype(np.float64)).sum() for b, n in enumerate(out["mel_lens"])])
+        wd = wav_digest(out["wav"], out["mel_lens"] * hop)
+        arrays["wav_strided_sel"] = out["wav"][sel][:, ::64].copy()
+        arrays["wav_stride"] = np.int64(64)
+        arrays["wav_sum"], arrays["wav_abs_sum"] = wd["wav_sum"], wd["wav_abs_sum"]
+    save(name, **arrays)
+
+
+def case_vocoder_micro(models):
+    """Per-op vocoder fixtures on the tiny config: conv_pre, every upsampler, every ResBlock1, conv_post."""
+    import torch
+    import torch.nn.functional as F
+    print("[voc_micro_tiny]", flush=True)
+    config = cfgmod.tiny_config()
+    voc_state = sw.make_vocoder_state(config, seed=4321)
+    v = models.HifiGan(config["models"]["hifigan"])
+    v.load_state_dict(sw.to_torch(voc_state), strict=True)
+    v.eval()
+    torch.set_grad_enabled(False)
+    rng = np.random.Generator(np.random.PCG64(77))
+    mel = rng.standard_normal((2, 80, 10)).astype(np.float32)
+    arrays = dict(mel=mel)
+    x = v.conv_pre(torch.from_numpy(mel))
+    arrays["conv_pre"] = x.numpy().copy()
+    for i in range(v.num_upsamples):
+        x = F.leaky_relu(x, 0.1)
+        x = v.ups[i](x)
+        arrays[f"ups{i}"] = x.numpy().copy()
+        xs = None
+        for j in range(v.num_kernels):
+            r = v.resblocks[i * v.num_kernels + j](x)
+            arrays[f"rb{i * v.num_kernels + j}"] = r.numpy().copy()
+            xs = r if xs is None else xs + r
+        x = xs / v.num_kernels
+        arrays[f"stage{i}"] = x.numpy().copy()
+    x = torch.tanh(v.conv_post(F.leaky_relu(x)))
+    arrays["wav"] = x.numpy().copy()
+    # weight-norm fold: the effective weight the reference convolves with
+    arrays["ups0_weight"] = v.ups[0].weight.detach().numpy().copy()
+    arrays["conv_pre_weight"] = v.conv_pre.weight.detach().numpy().copy()
+    save("voc_micro_tiny", **arrays)
+
+
+def case_tables(models):
+    """Both sinusoid tables as the reference builds them (U/blocks/utils.py:14-34, U/sublayers.py:28-44)."""
+    print("[tables]", flush=True)
+    from models.acoustic.unsupervised_fastspeech2.blocks.utils import get_sinusoid_encoding_table
+    from models.acoustic.unsupervised_fastspeech2.sublayers import SinusoidalPositionalEmbedding
+    from models.acoustic.unsupervised_fastspeech2.function import make_positions
+    import torch
+    t1 = get_sinusoid_encoding_table(300, 384).numpy()
+    t1b = get_sinusoid_encoding_table(1300, 64).numpy()
+    t2 = SinusoidalPositionalEmbedding.get_embedding(2048, 384, 0).numpy()
+    t2b = SinusoidalPositionalEmbedding.get_embedding(600, 64, 0).numpy()
+    x0 = np.array([[0.5, 0.0, -1.0, 2.0, 0.0, 0.0, 3.0], [0.0, 0.0, 1.0, 1.0, 1.0, 0.0, 0.0]], np.float32)
+    pos = make_positions(torch.from_numpy(x0), 0).numpy()
+    save("tables", fft_384_rows300=t1, fft_64_rows1300_tail=t1b[1000:], var_384_rows2048_stride8=t2[::8].copy(),
+         var_64_rows600=t2b, positions_in=x0, positions_out=pos)
+
+
+def case_host_loop():
+    """arrange_text / input_parse / combine_audio run from the reference source (API/utils.py:64-117)."""
+    print("[host_loop]", flush=True)
+    import torch
+    import torch.nn as nn
+    src = open(os.path.join(REF, "e2e_tts/src/api/utils.py")).read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TTS")
+    keep = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("arrange_text", "input_parse", "combine_audio")]
+    mod = ast.Module(body=[ast.ClassDef(name="HostLoop", bases=[], keywords=[], body=keep, decorator_list=[])], type_ignores=[])
+    ast.fix_missing_locations(mod)
+
+    def toy_tokenizer(txt):  # stand-in for g2p.text_to_sequence: one id per character
+        return [4 + (ord(c) % 127) for c in txt]
+
+    ns = {"torch": torch, "nn": nn, "np": np, "text_to_sequence": toy_tokenizer}
+    exec(compile(mod, "<reference API/utils.py TTS methods>", "exec"), ns)
+    hl = ns["HostLoop"]()
+    hl.max_len, hl.hop_length, hl.max_wav_value = 300, 256, 32768.0
+    rng = np.random.Generator(np.random.PCG64(5))
+    words = ["xin", "chao", "viet", "nam", "tieng", "noi", "tong", "hop", "am", "thanh"]
+
+    def sentence(n):
+        return " ".join(words[int(i)] for i in rng.integers(0, len(words), n))
+
+    texts = [sentence(6), " , ".join(sentence(int(rng.integers(8, 30))) for _ in range(9)), sentence(40), sentence(3),
+             " , ".join(sentence(12) for _ in range(5)), sentence(70), sentence(1)]
+    arranged = hl.arrange_text(list(texts))
+    batches, revert = hl.input_parse(list(texts))
+    arrays = dict(texts=np.array(texts), arranged=np.array(arranged), revert=revert.numpy(), n_batches=np.int64(len(batches)))
+    for i, (ids, lens) in enumerate(batches):
+        arrays[f"ids{i}"] = ids.numpy()
+        arrays[f"lens{i}"] = lens.numpy()
+    # a second, budget-stressing length list through the batching arithmetic only
+    lens_list = [120, 119, 100, 90, 90, 61, 60, 33, 30, 30, 12, 7, 300, 299, 150, 150, 1]
+    fake = ["a" * n for n in lens_list]
+    hl2 = ns["HostLoop"]()
+    hl2.max_len = 300
+    hl2.arrange_text = lambda t: t
+    b2, r2 = hl2.input_parse(fake)
+    arrays["stress_lens"] = np.asarray(lens_list, np.int64)
+    arrays["stress_revert"] = r2.numpy()
+    arrays["stress_batch_sizes"] = np.asarray([len(l) for _, l in b2], np.int64)
+    arrays["stress_batch_first_len"] = np.asarray([int(l[0]) for _, l in b2], np.int64)
+    # combine_audio
+    audios = [rng.uniform(-1.2, 1.2, 256 * 9).astype(np.float32), rng.uniform(-1, 1, 256 * 9).astype(np.float32),
+              np.array([0.99999, -0.99999, 1.0, -1.0, 0.5 / 32768, -0.5 / 32768, 1.5 / 32768] + [0.0] * (256 * 9 - 7), np.float32)]
+    lengths = [torch.tensor(7), torch.tensor(9), torch.tensor(2)]
+    pcm = hl.combine_audio(audios, lengths, 1000)
+    arrays.update(ca_audio0=audios[0], ca_audio1=audios[1], ca_audio2=audios[2], ca_lengths=np.array([7, 9, 2], np.int64),
+                  ca_distance=np.int64(1000), ca_pcm=pcm)
+    save("host_loop", **arrays)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--skip-large", action="store_true")
+    args = ap.parse_args()
+    models = import_reference()
+    tiny, full = cfgmod.tiny_config(), cfgmod.default_config()
+    jobs = {
+        "tables": lambda: case_tables(models),
+        "host_loop": case_host_loop,
+        "voc_micro_tiny": lambda: case_vocoder_micro(models),
+        "tiny_b3": lambda: case_model(models, "tiny_b3", tiny, "varied", [23, 17, 9], 1, (1.0, 1.0, 1.0), 100, 2e-3, "full"),
+        "tiny_long": lambda: case_model(models, "tiny_long", tiny, "varied", [70, 33], 2, (1.0, 1.0, 1.0), 200, 2e-3, "full"),
+        "tiny_ctl": lambda: case_model(models, "tiny_ctl", tiny, "varied", [12, 30, 30, 5], 0, (1.3, 0.9, 1.1), 300, 2e-3, "full"),
+        "tiny_b1": lambda: case_model(models, "tiny_b1", tiny, "varied", [1], 3, (1.0, 1.0, 1.0), 400, 2e-3, "full"),
+        "c1_plumbing": lambda: case_model(models, "c1_plumbing", full, "varied", [40], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
+        "full_b3": lambda: case_model(models, "full_b3", full, "varied", [48, 31, 20], 1, (1.0, 1.0, 1.0), 500, 1e-3, "medium"),
+    }
+    large = {
+        "c2_latency": lambda: case_model(models, "c2_latency", full, "fixed", [128], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
+        "c3_mixed": lambda: case_model(models, "c3_mixed", full, "fixed", c3_lengths(), 1, (1.0, 1.0, 1.0), 2, 1e-4, "digest", max_tries=60),
+    }
+    if not args.skip_large:
+        jobs.update(large)
+    for name, fn in jobs.items():
+        if args.only and name != args.only:
+            continue
+        fn()
+
+
+def c3_lengths():
+    """B = 32, lengths linspace(40, 200, 32) rounded, shuffled with PCG64(2)."""
+    lens = np.round(np.linspace(40, 200, 32)).astype(np.int64)
+    np.random.Generator(np.random.PCG64(2)).shuffle(lens)
+    return [int(x) for x in lens]
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU test that takes more than a few seconds")
+
+
+def load_golden(name):
+    path = os.path.join(GOLD, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"golden fixture {name} not generated")
+    return dict(np.load(path, allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def config_for(name):
+    from e2e_tts_amd import config as cfgmod
+    return cfgmod.tiny_config() if name.startswith("tiny") or name.startswith("voc_micro") else cfgmod.default_config()
+
+
+_STATE_CACHE = {}
+
+
+def states_for(g, name):
+    """Regenerate the synthetic state dicts a fixture was made with (seeds + mode are stored in it)."""
+    from e2e_tts_amd import config as cfgmod, synth_weights as sw
+    cfg = config_for(name)
+    key = (name.startswith("tiny"), str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
+    if key not in _STATE_CACHE:
+        ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=int(g["weight_seeds"][0]), mode=str(g["mode"]))
+        voc = sw.make_vocoder_state(cfg, seed=int(g["weight_seeds"][1]))
+        _STATE_CACHE[key] = (ac, voc)
+    return (cfg,) + _STATE_CACHE[key]

@@ -1,0 +1,118 @@
+"""The numpy oracle against every fixture generated from the reference (CPU, -m "not gpu").
+
+Bars (SURVEY.md 8(d) parity gates): durations / mel_lens / pitch + energy bucket
+indices exact; mel_post and wav mean-L1 <= 1e-4 (measured fp32 noise floor is
+~5e-7 / ~5e-9, so the oracle is held to 1e-5 here).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, states_for
+from e2e_tts_amd import config as cfgmod
+from oracle import ref_numpy as orc
+
+MODEL_CASES = ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1", "c1_plumbing", "full_b3"]
+
+
+def mean_l1(a, b):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).mean())
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_acoustic_and_vocoder_match_reference(name):
+    g = load_golden(name)
+    cfg, ac_state, voc_state = states_for(g, name)
+    ac = orc.AcousticOracle(ac_state, cfg, cfgmod.DEFAULT_STATS)
+    d, p, e = (float(x) for x in g["controls"])
+    (mel, mel_post, dur), mel_lens = ac.inference(np.array([int(g["speaker"])]), g["ids"], g["lens"], d, p, e)
+    np.testing.assert_array_equal(dur, g["dur"])
+    np.testing.assert_array_equal(mel_lens, g["mel_lens"])
+    np.testing.assert_array_equal(ac.trace["pitch_idx"], g["pitch_idx"])
+    np.testing.assert_array_equal(ac.trace["energy_idx"], g["energy_idx"])
+    assert mean_l1(ac.trace["log_d"], g["log_d"]) < 1e-5
+    assert mean_l1(ac.trace["pitch_pred"], g["pitch_pred"]) < 1e-5
+    assert mean_l1(mel, g["mel"]) < 1e-5
+    assert mean_l1(mel_post, g["mel_post"]) < 1e-5
+    for k in ("enc_out", "lr_out", "dec_out"):
+        if k in g:
+            assert mean_l1(ac.trace[k], g[k]) < 1e-5, k
+    voc = orc.VocoderOracle(voc_state, cfg)
+    wav = voc.forward(g["mel_post"].transpose(0, 2, 1))[:, 0]
+    if "wav" in g:
+        assert wav.shape == g["wav"].shape
+        assert mean_l1(wav, g["wav"]) < 1e-5
+        assert np.abs(wav - g["wav"]).max() < 1e-4
+    else:
+        s = int(g["wav_stride"])
+        assert mean_l1(wav[:, ::s], g["wav_strided"]) < 1e-5
+        assert mean_l1(wav[:, :2048], g["wav_head"]) < 1e-5
+        hop = cfg["audio"]["stft"]["hop_length"]
+        for b, n in enumerate(g["mel_lens"] * hop):
+            assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < 1e-5 * n
+
+
+def test_vocoder_stages_match_reference():
+    g = load_golden("voc_micro_tiny")
+    cfg = cfgmod.tiny_config()
+    from e2e_tts_amd import synth_weights as sw
+    voc = orc.VocoderOracle(sw.make_vocoder_state(cfg, seed=4321), cfg)
+    np.testing.assert_allclose(voc.w["ups.0.weight"], g["ups0_weight"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(voc.w["conv_pre.weight"], g["conv_pre_weight"], rtol=0, atol=1e-7)
+    hg = cfg["models"]["hifigan"]
+    x = orc.conv1d(g["mel"], voc.w["conv_pre.weight"], voc.w["conv_pre.bias"], padding=3)
+    assert mean_l1(x, g["conv_pre"]) < 1e-6
+    nk = len(hg["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(hg["upsample_rates"], hg["upsample_kernel_sizes"])):
+        # each op is checked from the reference's own input to it (no error accumulation)
+        xin = g["conv_pre"] if i == 0 else g[f"stage{i - 1}"]
+        up = orc.conv_transpose1d(orc.leaky_relu(xin, 0.1), voc.w[f"ups.{i}.weight"], voc.w[f"ups.{i}.bias"], u, (k - u) // 2)
+        assert up.shape == g[f"ups{i}"].shape
+        assert mean_l1(up, g[f"ups{i}"]) < 1e-6
+        for j in range(nk):
+            r = voc.resblock(i * nk + j, g[f"ups{i}"], hg["resblock_kernel_sizes"][j], hg["resblock_dilation_sizes"][j])
+            assert mean_l1(r, g[f"rb{i * nk + j}"]) < 1e-6
+    wav = voc.forward(g["mel"])
+    assert mean_l1(wav, g["wav"]) < 1e-6
+
+
+def test_tables_match_reference():
+    g = load_golden("tables")
+    np.testing.assert_array_equal(orc.sinusoid_table(300, 384), g["fft_384_rows300"])
+    np.testing.assert_array_equal(orc.sinusoid_table(1300, 64)[1000:], g["fft_64_rows1300_tail"])
+    # angle = pos * freq in fp32; a 1-ulp difference in exp() moves it by pos * 6e-8, so the bar scales with pos
+    t = orc.fairseq_sinusoid_table(2048, 384, 0)[::8]
+    pos = np.arange(0, 2048, 8)[:, None]
+    assert (np.abs(t - g["var_384_rows2048_stride8"]) <= 1e-6 + 2.5e-7 * pos).all()
+    t = orc.fairseq_sinusoid_table(600, 64, 0)
+    assert (np.abs(t - g["var_64_rows600"]) <= 1e-6 + 2.5e-7 * np.arange(600)[:, None]).all()
+    np.testing.assert_array_equal(orc.make_positions(g["positions_in"], 0), g["positions_out"])
+    from e2e_tts_amd import synth_weights as sw
+    np.testing.assert_array_equal(sw.sinusoid_table(300, 384), g["fft_384_rows300"])
+
+
+def test_host_loop_matches_reference():
+    g = load_golden("host_loop")
+    texts = [str(t) for t in g["texts"]]
+    arranged = orc.arrange_text(list(texts), 300)
+    assert arranged == [str(t) for t in g["arranged"]]
+    seqs = [[4 + (ord(c) % 127) for c in t] for t in arranged]
+    order, revert, spans = orc.pack_batches([len(s) for s in seqs], 300)
+    np.testing.assert_array_equal(revert, g["revert"])
+    assert len(spans) == int(g["n_batches"])
+    for i, (s, e) in enumerate(spans):
+        lens = np.array([len(seqs[j]) for j in order[s:e]])
+        np.testing.assert_array_equal(lens, g[f"lens{i}"])
+        ids = np.zeros((e - s, lens.max()), np.int64)
+        for r, j in enumerate(order[s:e]):
+            ids[r, :len(seqs[j])] = seqs[j]
+        np.testing.assert_array_equal(ids, g[f"ids{i}"])
+    order, revert, spans = orc.pack_batches(g["stress_lens"], 300)
+    # torch.sort(descending=True) is not stable, so equal-length items may swap places (API/utils.py:84);
+    # the sorted length sequence, and hence the batches, must agree.
+    ref_order = np.argsort(g["stress_revert"])
+    np.testing.assert_array_equal(g["stress_lens"][order], g["stress_lens"][ref_order])
+    np.testing.assert_array_equal(order[revert], np.arange(len(order)))
+    np.testing.assert_array_equal([e - s for s, e in spans], g["stress_batch_sizes"])
+    np.testing.assert_array_equal([g["stress_lens"][order[s]] for s, _ in spans], g["stress_batch_first_len"])
+    pcm = orc.combine_audio([g["ca_audio0"], g["ca_audio1"], g["ca_audio2"]], g["ca_lengths"], int(g["ca_distance"]))
+    np.testing.assert_array_equal(pcm, g["ca_pcm"])

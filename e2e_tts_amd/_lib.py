@@ -1,0 +1,236 @@
+"""ctypes binding of include/e2etts.h (libe2etts_hip.so).  There is no CPU fallback: if the
+library is missing or no GPU is visible, construction raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .config import CEngineConfig, EngineDims
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libe2etts_hip.so")
+
+E_OK, E_INVAL, E_HIP, E_STATE, E_NOMEM, E_KEY = 0, -1, -2, -3, -4, -5
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library (built by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  e2e_tts_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P, I, F, SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    lib.e2etts_version.restype = C.c_char_p
+    lib.e2etts_version.argtypes = []
+    lib.e2etts_last_error.restype = C.c_char_p
+    lib.e2etts_last_error.argtypes = [P]
+    lib.e2etts_create.restype = I
+    lib.e2etts_create.argtypes = [I, C.POINTER(CEngineConfig), C.POINTER(P)]
+    lib.e2etts_destroy.restype = None
+    lib.e2etts_destroy.argtypes = [P]
+    lib.e2etts_load_weights.restype = I
+    lib.e2etts_load_weights.argtypes = [P, P, SZ]
+    lib.e2etts_acoustic.restype = I
+    lib.e2etts_acoustic.argtypes = [P, P, P, I, I, P, I, F, F, F, P, P, C.POINTER(I), P, P, P, P, P]
+    lib.e2etts_fetch_mel.restype = I
+    lib.e2etts_fetch_mel.argtypes = [P, P, P]
+    lib.e2etts_fetch_tap.restype = I
+    lib.e2etts_fetch_tap.argtypes = [P, C.c_char_p, P, SZ]
+    lib.e2etts_vocoder.restype = I
+    lib.e2etts_vocoder.argtypes = [P, P, I, I, P, P]
+    lib.e2etts_vocoder_btc.restype = I
+    lib.e2etts_vocoder_btc.argtypes = [P, P, I, I, P, P]
+    lib.e2etts_synthesize.restype = I
+    lib.e2etts_synthesize.argtypes = [P, P, P, I, I, P, I, F, F, F, P, SZ, P, C.POINTER(I)]
+    lib.e2etts_fetch_pcm.restype = I
+    lib.e2etts_fetch_pcm.argtypes = [P, P, SZ]
+    lib.e2etts_fetch_wav.restype = I
+    lib.e2etts_fetch_wav.argtypes = [P, P, SZ]
+    lib.e2etts_profile_enable.restype = I
+    lib.e2etts_profile_enable.argtypes = [P, I]
+    lib.e2etts_profile_read.restype = I
+    lib.e2etts_profile_read.argtypes = [P, C.POINTER(KernelStat), I]
+    lib.e2etts_device_bytes.restype = SZ
+    lib.e2etts_device_bytes.argtypes = [P]
+    lib.e2etts_stream.restype = P
+    lib.e2etts_stream.argtypes = [P]
+    lib.e2etts_sync.restype = I
+    lib.e2etts_sync.argtypes = [P]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "e2etts_version", "e2etts_last_error", "e2etts_create", "e2etts_destroy", "e2etts_load_weights", "e2etts_acoustic",
+    "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
+    "e2etts_fetch_wav", "e2etts_profile_enable", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
+]
+
+
+def _addr(x) -> Optional[int]:
+    """Raw address of a numpy array (host) or torch tensor (host or HBM); None stays NULL."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.data_ptr()
+    raise TypeError(f"cannot take the address of {type(x)}")
+
+
+class Engine:
+    """One GPU, one stream, one set of weights.  Thin, typed wrapper over the C ABI."""
+
+    def __init__(self, dims: EngineDims, device: int = 0):
+        self.lib = load_library()
+        self.dims = dims
+        self._h = C.c_void_p()
+        cfg = dims.to_c()
+        rc = self.lib.e2etts_create(int(device), C.byref(cfg), C.byref(self._h))
+        if rc != E_OK:
+            msg = self.lib.e2etts_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise (ValueError if rc == E_INVAL else RuntimeError)(f"e2etts_create: {msg}")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.e2etts_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc >= 0:
+            return rc
+        msg = f"{what}: {self.lib.e2etts_last_error(self._h).decode()}"
+        if rc == E_INVAL:
+            raise ValueError(msg)
+        if rc == E_KEY:
+            raise KeyError(msg)
+        if rc == E_NOMEM:
+            raise MemoryError(msg)
+        raise RuntimeError(msg)
+
+    # ---- weights
+    def load_weights(self, blob) -> None:
+        """blob: uint8 numpy array (host) or uint8 torch tensor (host / HBM, e.g. after a RCCL broadcast)."""
+        n = blob.nbytes if isinstance(blob, np.ndarray) else blob.numel() * blob.element_size()
+        self._check(self.lib.e2etts_load_weights(self._h, _addr(blob), n), "e2etts_load_weights")
+
+    # ---- acoustic model
+    def acoustic(self, ids, lens, speaker, d_control=1.0, p_control=1.0, e_control=1.0, want=("dur", "mel_lens")):
+        """ids [B, L] int64, lens [B] int64, speaker [1 or B] int64 (numpy or torch, host or device).
+        Returns dict with T and the requested host arrays."""
+        B, L = int(ids.shape[0]), int(ids.shape[1])
+        n_spk = int(speaker.shape[0])
+        out = {}
+        bufs = dict(
+            dur=np.empty((B, L), np.float32) if "dur" in want else None,
+            mel_lens=np.empty((B,), np.int64) if "mel_lens" in want else None,
+            pitch_idx=np.empty((B, L), np.int32) if "pitch_idx" in want else None,
+            energy_idx=np.empty((B, L), np.int32) if "energy_idx" in want else None,
+            log_d=np.empty((B, L), np.float32) if "log_d" in want else None,
+            pitch_pred=np.empty((B, L, 2), np.float32) if "pitch_pred" in want else None,
+            energy_pred=np.empty((B, L), np.float32) if "energy_pred" in want else None,
+        )
+        T = C.c_int(0)
+        rc = self.lib.e2etts_acoustic(self._h, _addr(ids), _addr(lens), B, L, _addr(speaker), n_spk,
+                                      float(d_control), float(p_control), float(e_control),
+                                      _addr(bufs["dur"]), _addr(bufs["mel_lens"]), C.byref(T), _addr(bufs["pitch_idx"]),
+                                      _addr(bufs["energy_idx"]), _addr(bufs["log_d"]), _addr(bufs["pitch_pred"]),
+                                      _addr(bufs["energy_pred"]))
+        self._check(rc, "e2etts_acoustic")
+        out.update({k: v for k, v in bufs.items() if v is not None})
+        out["T"] = T.value
+        out["B"] = B
+        return out
+
+    def fetch_mel(self, B: int, T: int, mel=True, mel_post=True, out_mel=None, out_mel_post=None):
+        m = out_mel if out_mel is not None else (np.empty((B, T, self.dims.n_mel), np.float32) if mel else None)
+        mp = out_mel_post if out_mel_post is not None else (np.empty((B, T, self.dims.n_mel), np.float32) if mel_post else None)
+        self._check(self.lib.e2etts_fetch_mel(self._h, _addr(m), _addr(mp)), "e2etts_fetch_mel")
+        return m, mp
+
+    def fetch_tap(self, which: str, shape) -> np.ndarray:
+        out = np.empty(shape, np.float32)
+        self._check(self.lib.e2etts_fetch_tap(self._h, which.encode(), _addr(out), out.size), "e2etts_fetch_tap")
+        return out
+
+    # ---- vocoder
+    def vocoder(self, mel, B: int, T: int, channels_first=True, wav=True, pcm=False, out_wav=None, out_pcm=None):
+        """mel: [B, n_mel, T] (channels_first) or [B, T, n_mel], or None for the resident mel_post."""
+        n = B * T * self.dims.hop_length
+        w = out_wav if out_wav is not None else (np.empty((B, T * self.dims.hop_length), np.float32) if wav else None)
+        p = out_pcm if out_pcm is not None else (np.empty((B, T * self.dims.hop_length), np.int16) if pcm else None)
+        fn = self.lib.e2etts_vocoder if channels_first else self.lib.e2etts_vocoder_btc
+        self._check(fn(self._h, _addr(mel), B, T, _addr(w), _addr(p)), "e2etts_vocoder")
+        del n
+        return w, p
+
+    # ---- end to end
+    def synthesize(self, ids, lens, speaker, d_control=1.0, p_control=1.0, e_control=1.0, fetch_pcm=True,
+                   out_pcm=None, out_mel_lens=None):
+        """One batch of TTS.inference: returns (pcm [B, T*hop] int16 or None, mel_lens [B], T)."""
+        B, L = int(ids.shape[0]), int(ids.shape[1])
+        mel_lens = out_mel_lens if out_mel_lens is not None else np.empty((B,), np.int64)
+        T = C.c_int(0)
+        cap = 0
+        if out_pcm is not None:
+            cap = out_pcm.size if isinstance(out_pcm, np.ndarray) else out_pcm.numel()
+        rc = self.lib.e2etts_synthesize(self._h, _addr(ids), _addr(lens), B, L, _addr(speaker), int(speaker.shape[0]),
+                                        float(d_control), float(p_control), float(e_control), _addr(out_pcm), cap,
+                                        _addr(mel_lens), C.byref(T))
+        self._check(rc, "e2etts_synthesize")
+        pcm = out_pcm
+        if out_pcm is None and fetch_pcm:
+            pcm = np.empty((B, T.value * self.dims.hop_length), np.int16)
+            self._check(self.lib.e2etts_fetch_pcm(self._h, _addr(pcm), pcm.size), "e2etts_fetch_pcm")
+        return pcm, mel_lens, T.value
+
+    def fetch_wav(self, B: int, T: int) -> np.ndarray:
+        w = np.empty((B, T * self.dims.hop_length), np.float32)
+        self._check(self.lib.e2etts_fetch_wav(self._h, _addr(w), w.size), "e2etts_fetch_wav")
+        return w
+
+    # ---- profiling
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.e2etts_profile_enable(self._h, 1 if on else 0), "e2etts_profile_enable")
+
+    def profile_read(self):
+        arr = (KernelStat * 64)()
+        n = self._check(self.lib.e2etts_profile_read(self._h, arr, 64), "e2etts_profile_read")
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms), flops=float(arr[i].flops),
+                     bytes=float(arr[i].bytes)) for i in range(min(n, 64))]
+
+    def device_bytes(self) -> int:
+        return int(self.lib.e2etts_device_bytes(self._h))
+
+    def sync(self):
+        self._check(self.lib.e2etts_sync(self._h), "e2etts_sync")
+
+    def stream(self) -> int:
+        return int(self.lib.e2etts_stream(self._h) or 0)

@@ -1,0 +1,167 @@
+// Fused masked multi-head self-attention for one FFT block (fp32, flash-style, never materialises [N, N]).
+//
+// Replaces reference U/blocks/transformer.py:224-236 + 251-261: head split, bmm(q, k^T) / sqrt(d_k),
+// masked_fill(key padding, -inf), softmax over keys, bmm(attn, v), head merge.  The reference materialises
+// (2B) x N x N scores (151 MB at B = 32, T = 768); here a workgroup of 4 wavefronts owns 128 queries of one
+// (utterance, head) and walks the keys in chunks of 32 staged in LDS, keeping running max / sum per query.
+//
+// MFMA orientation (v_mfma_f32_32x32x2_f32): S^T = K . Q^T puts the QUERY on the lane (column) and the 32 keys
+// of the chunk in the 16 accumulator registers x 2 lane halves.  Then
+//   - the softmax row reduction is 16 in-lane ops + one cross-half shuffle (wavefront shuffle, no LDS);
+//   - the probabilities are already the B operand of O^T += V^T . P^T: register r of lane half h holds key
+//     k0(r) + 4h, k0(r) = (r & 3) + 8 (r >> 2), and MFMA step r consumes exactly the key pair {k0(r), k0(r) + 4}.
+#include <math.h>
+
+#include "kernels.h"
+
+namespace e2etts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+template <int DK>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                        const int32_t* __restrict__ lens, int N, int H, float temperature) {
+  constexpr int LDS_LD = DK + 4;
+  constexpr int DT = DK / 32;  // 32-wide tiles of the head dimension
+  constexpr int QQ = DK / 8;   // float4 fragments per query row and lane half
+  __shared__ __attribute__((aligned(16))) float Ks[32 * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * LDS_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int len = min(lens ? lens[b] : N, N);
+  const int ld = 3 * H;
+  const float* base = qkv + (long long)b * N * ld;
+  const float* qp = base + head * DK;
+  const float* kp = base + H + head * DK;
+  const float* vp = base + 2 * H + head * DK;
+
+  // Q fragments: lane (query li, half lh) holds Q[q][8 qq + 4 lh + r]
+  float4 qf[QQ];
+  {
+    const int qrow = min(q0 + li, N - 1);
+    const float* qr = qp + (long long)qrow * ld + lh * 4;
+#pragma unroll
+    for (int qq = 0; qq < QQ; ++qq) qf[qq] = *reinterpret_cast<const float4*>(qr + qq * 8);
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nchunks = (len + 31) / 32;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    __syncthreads();
+    for (int i = tid; i < 32 * (DK / 4); i += 256) {
+      const int r = i / (DK / 4), c = (i % (DK / 4)) * 4;
+      const int key = kc * 32 + r;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (key < N) {
+        kv = *reinterpret_cast<const float4*>(kp + (long long)key * ld + c);
+        vv = *reinterpret_cast<const float4*>(vp + (long long)key * ld + c);
+      }
+      *reinterpret_cast<float4*>(Ks + r * LDS_LD + c) = kv;
+      *reinterpret_cast<float4*>(Vs + r * LDS_LD + c) = vv;
+    }
+    __syncthreads();
+
+    // S^T[key][query] = sum_d K[key][d] Q[query][d]
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float* ka = Ks + li * LDS_LD + lh * 4;
+#pragma unroll
+    for (int qq = 0; qq < QQ; ++qq) {
+      const float4 a = *reinterpret_cast<const float4*>(ka + qq * 8);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[qq].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[qq].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[qq].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[qq].w, s, 0, 0, 0);
+    }
+    // scale, key-padding mask, online softmax (per query = per lane, both lane halves hold the same query)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = s[r] / temperature;
+      v = key < len ? v : -INFINITY;
+      s[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);  // finite: chunk kc has at least one valid key
+    const float corr = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = expf(s[r] - m_new);
+      s[r] = pv;
+      psum += pv;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+    // O^T[d][query] = O^T * corr + sum_key V[key][d] P[key][query]
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float a = Vs[key * LDS_LD + d * 32 + li];
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  // O^T tile d: column = query (lane & 31), row = head-dim offset (r & 3) + 8 (r >> 2) + 4 lh -> 4 x float4 per tile
+  const int q = q0 + li;
+  if (q < N) {
+    const bool valid = q < len;
+    const float inv = valid ? 1.0f / l_run : 0.f;
+    float* orow = out + ((long long)b * N + q) * H + head * DK + 4 * lh;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        v.x = valid ? o[d][4 * g + 0] * inv : 0.f;
+        v.y = valid ? o[d][4 * g + 1] * inv : 0.f;
+        v.z = valid ? o[d][4 * g + 2] * inv : 0.f;
+        v.w = valid ? o[d][4 * g + 3] * inv : 0.f;
+        *reinterpret_cast<float4*>(orow + d * 32 + 8 * g) = v;
+      }
+  }
+}
+
+}  // namespace
+
+const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head,
+                             hipStream_t s) {
+  if (!qkv || !out) return "attention: null pointer";
+  if (B <= 0 || N <= 0 || n_head <= 0 || H % n_head) return "attention: bad dims";
+  if (((uintptr_t)qkv | (uintptr_t)out) & 15) return "attention: buffers must be 16-byte aligned";
+  const int dk = H / n_head;
+  // reference: temperature = np.power(d_k, 0.5), scores divided by it in fp32 (U/blocks/transformer.py:201,254)
+  const float temperature = (float)sqrt((double)dk);
+  dim3 grid((N + 127) / 128, n_head, B);
+  switch (dk) {
+    case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+    case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+    case 96: hipLaunchKernelGGL(attention_kernel<96>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+    case 128: hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+    case 192: hipLaunchKernelGGL(attention_kernel<192>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+    default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
+  }
+  return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
+}
+
+}  // namespace e2etts

@@ -1,0 +1,202 @@
+// conv_gemm: "same" 1-D convolution / Linear as an implicit GEMM on the gfx950 fp32 matrix cores.
+//
+// This one kernel carries ~99 % of the hot path's FLOPs: every Conv1d / Linear of the FastSpeech2 FFT
+// blocks (reference U/blocks/transformer.py:213-240, 289-297), the predictors (U/layers.py:410-420,
+// 491-505), mel_linear (U/model.py:186), the Postnet (U/layers.py:556-563), and HiFi-GAN's conv_pre,
+// polyphase-rewritten ConvTranspose1d upsamplers and ResBlock1 dilated convolutions
+// (V/generator.py:37-53, V/layers.py:33-40).
+//
+// Mapping (channels-last activations [B, T, C], weights [Cout, KW*Cin] tap-major):
+//   M = time positions of one utterance, N = Cout, K = KW * Cin.
+//   D[t][n] += A[t][k] * B[k][n] with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD).
+// A workgroup (4 wavefronts of 64) owns a BM x BN output tile.  For each 32-channel chunk of Cin it stages
+// ONE activation slab of (BM + dil*(KW-1)) rows in LDS -- the taps of a dilated convolution are row-shifted
+// views of that slab, so the input is read from HBM/L2 once per chunk, not once per tap -- and streams the
+// per-tap weight tiles through a double-buffered LDS tile, prefetched into registers behind the MFMAs.
+// LDS rows are 36 floats (32 + 4 pad): a ds_read_b128 of 16 consecutive rows then covers all 64 banks once.
+// Operand fragments are read as float4 = 4 consecutive k; lane half h supplies k = 8q + 4h + r to MFMA r,
+// for both operands, so the k order inside an 8-wide group is permuted identically for A and B.
+#include "kernels.h"
+
+namespace e2etts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;   // channels per K chunk
+constexpr int LDK = 36;  // padded LDS row stride (floats)
+constexpr int MAX_HALO = 64;
+
+__device__ __forceinline__ float4 lrelu4(float4 v, float slope) {
+  v.x = v.x >= 0.f ? v.x : v.x * slope;
+  v.y = v.y >= 0.f ? v.y : v.y * slope;
+  v.z = v.z >= 0.f ? v.z : v.z * slope;
+  v.w = v.w >= 0.f ? v.w : v.w * slope;
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+  constexpr int NWN = BN / WN;
+  constexpr int MT = WM / 32, NT = WN / 32;
+  static_assert((BM / WM) * NWN == 4, "4 wavefronts per workgroup");
+  constexpr int BROWS = BN / 32;  // B-tile rows staged per thread
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int halo = p.dil * (p.KW - 1);
+  const int arows = BM + halo;
+  float* As = smem;
+  float* Bs = smem + arows * LDK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const float* in_b = p.in + (long long)b * p.in_bs;
+  const int KC = p.KW * p.Cin;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int nchunk = (p.Cin + BK - 1) / BK;
+  const int niter = nchunk * p.KW;
+  float4 breg[BROWS];
+
+  auto load_b = [&](int it) {
+    const int chunk = it / p.KW, j = it - chunk * p.KW;
+    const int c = chunk * BK + lc4;
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+      const int n = n0 + lrow + i * 32;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < p.Cout && c < p.Cin) v = *reinterpret_cast<const float4*>(p.w + (long long)n * KC + j * p.Cin + c);
+      breg[i] = v;
+    }
+  };
+  auto store_b = [&](int buf) {
+    float* dst = Bs + buf * (BN * LDK);
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(dst + (lrow + i * 32) * LDK + lc4) = breg[i];
+  };
+
+  load_b(0);
+  store_b(0);
+  int cur = 0;
+  for (int it = 0; it < niter; ++it) {
+    const int chunk = it / p.KW, j = it - chunk * p.KW;
+    if (j == 0) {
+      if (it != 0) __syncthreads();  // every wave is done reading the previous slab
+      const int c = chunk * BK + lc4;
+      const bool cok = c < p.Cin;
+      for (int r = lrow; r < arows; r += 32) {
+        const int t = t0 - p.pad + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && t >= 0 && t < p.T) {
+          v = *reinterpret_cast<const float4*>(in_b + (long long)t * p.in_ld + c);
+          if (p.in_slope != 1.0f) v = lrelu4(v, p.in_slope);
+        }
+        *reinterpret_cast<float4*>(As + r * LDK + lc4) = v;
+      }
+    }
+    if (it + 1 < niter) load_b(it + 1);  // global loads in flight behind the MFMAs below
+    __syncthreads();
+
+    const float* a_base = As + (wm * WM + li + j * p.dil) * LDK + lh * 4;
+    const float* b_base = Bs + cur * (BN * LDK) + (wn * WN + li) * LDK + lh * 4;
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      float4 af[MT], bf[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + q * 8);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + q * 8);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
+        }
+    }
+    if (it + 1 < niter) store_b(cur ^ 1);  // that buffer was last read before this iteration's barrier
+    cur ^= 1;
+  }
+
+  // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  const int len = p.lens ? p.lens[b] : p.T;
+  float* out_b = p.out + (long long)b * p.out_bs;
+  const float* res_b = p.res ? p.res + (long long)b * p.res_bs : nullptr;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = n0 + wn * WN + n * 32 + li;
+    if (col >= p.Cout) continue;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = t0 + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (t >= p.T) continue;
+        float v = acc[m][n][r] + bias;
+        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == ACT_TANH) v = tanhf(v);
+        else if (p.act == ACT_LRELU) v = v >= 0.f ? v : v * p.act_slope;
+        if (res_b) v += res_b[(long long)t * p.res_ld + col];
+        if (t >= len) v = 0.f;
+        float* o = out_b + (long long)t * p.out_ld + col;
+        if (p.accumulate) v += *o;
+        if (p.out_div != 1.0f) v = v / p.out_div;
+        *o = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+const char* launch_cfg(const ConvParams& p, hipStream_t s) {
+  const int halo = p.dil * (p.KW - 1);
+  const size_t lds = (size_t)((BM + halo) * LDK + 2 * BN * LDK) * sizeof(float);
+  if (lds > 64 * 1024) return "conv_gemm: LDS tile exceeds 64 KiB";
+  dim3 grid((p.T + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.B);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
+  return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
+}
+
+}  // namespace
+
+double conv_gemm_flops(const ConvParams& p) { return 2.0 * p.B * (double)p.T * p.Cout * p.KW * p.Cin; }
+
+double conv_gemm_bytes(const ConvParams& p) {
+  double e = (double)p.B * p.T * (p.Cin + p.Cout * (1.0 + (p.res ? 1 : 0) + (p.accumulate ? 1 : 0)));
+  e += (double)p.Cout * p.KW * p.Cin;
+  return 4.0 * e;
+}
+
+const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
+  if (!p.in || !p.w || !p.out) return "conv_gemm: null pointer";
+  if (p.B <= 0 || p.T <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.KW <= 0 || p.dil <= 0) return "conv_gemm: bad dims";
+  if (p.Cin % 4 || p.in_ld % 4) return "conv_gemm: Cin and in_ld must be multiples of 4";
+  if (((uintptr_t)p.in | (uintptr_t)p.w) & 15) return "conv_gemm: in / w must be 16-byte aligned";
+  if ((p.in_bs % 4) != 0) return "conv_gemm: in_bs must be a multiple of 4";
+  if (p.in_ld < p.Cin || p.out_ld < p.Cout || (p.res && p.res_ld < p.Cout)) return "conv_gemm: row stride < channels";
+  if (p.dil * (p.KW - 1) > MAX_HALO) return "conv_gemm: dilation * (KW - 1) exceeds the slab halo limit";
+  if (p.pad < 0 || p.pad > p.dil * (p.KW - 1)) return "conv_gemm: pad out of range";
+  if (p.Cout > 64) return launch_cfg<128, 128, 64, 64>(p, s);
+  if (p.Cout > 32) return launch_cfg<256, 64, 64, 64>(p, s);
+  return launch_cfg<256, 32, 64, 32>(p, s);
+}
+
+}  // namespace e2etts

@@ -1,0 +1,945 @@
+// Engine + C ABI (include/e2etts.h): owns the weights, the workspace, one HIP stream, and sequences the
+// kernels of kernels.h into the reference's inference path
+//   UnsupervisedFastSpeech2.inference (reference U/model.py:155-194)  ->  HifiGan.forward (V/generator.py:37-53)
+// exactly as TTS.inference drives them per batch (API/utils.py:130-148).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/e2etts.h"
+#include "kernels.h"
+
+using namespace e2etts;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct BlobHeader {
+  char magic[8];
+  uint32_t version;
+  uint32_t n_entries;
+  uint64_t data_offset;
+  uint64_t total_bytes;
+};
+struct BlobEntry {
+  char name[64];
+  uint64_t offset;
+  uint64_t numel;
+};
+
+struct FFTLayer {
+  const float *wqkv, *bqkv, *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+};
+struct PredLayer {
+  const float *w, *b, *g, *beta;
+};
+struct Predictor {
+  std::vector<PredLayer> layers;
+  const float *lin_w = nullptr, *lin_b = nullptr, *alpha = nullptr;
+  int kernel = 0, chans = 0, odim = 0;
+};
+struct ConvW {
+  const float *w = nullptr, *b = nullptr;
+};
+
+struct ProfRec {
+  hipEvent_t start, stop;
+  int cls;
+  double flops, bytes;
+};
+
+}  // namespace
+
+struct e2etts_engine {
+  e2etts_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::string err;
+  size_t dev_bytes = 0;
+
+  // weights
+  DevBuf blob;
+  std::map<std::string, std::pair<const float*, uint64_t>> tensors;
+  bool loaded = false;
+  std::vector<FFTLayer> enc, dec;
+  Predictor dur, pitch, energy;
+  const float *emb = nullptr, *enc_pos = nullptr, *dec_pos = nullptr, *pos_regen = nullptr, *spk_emb = nullptr;
+  const float *var_pos = nullptr, *pitch_emb = nullptr, *energy_emb = nullptr, *energy_bins = nullptr;
+  uint64_t var_pos_rows = 0;
+  ConvW mel_lin, voc_pre, voc_post;
+  std::vector<ConvW> postnet, voc_up;
+  std::vector<std::vector<ConvW>> rb_c1, rb_c2;  // [stage * n_kernels + j][dilation index]
+
+  // workspace
+  DevBuf ids, lens64, lens32, spk, xa, xb, xs, xp, tmp, qkv, att, hid, p1, p2;
+  DevBuf logd, durf, cum, mel64, mel32, posbuf, ppred, epred, pidx, eidx;
+  DevBuf dx, dxb, mel, melpost, pn1, pn2, encout;
+  DevBuf melin, v0, v1, v2, v3, wav, pcm;
+  int64_t* h_mel = nullptr;  // pinned
+  int last_B = 0, last_L = 0, last_T = 0, voc_B = 0, voc_T = 0;
+  bool have_acoustic = false, have_wav = false;
+
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<e2etts_kernel_stat> prof_stats;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
+
+namespace {
+
+#define HIPCHK(e, expr)                                                                     \
+  do {                                                                                      \
+    hipError_t _s = (expr);                                                                 \
+    if (_s != hipSuccess) return (e)->fail(E2ETTS_EHIP, "%s: %s", #expr, hipGetErrorString(_s)); \
+  } while (0)
+
+#define RET(expr)            \
+  do {                       \
+    int _r = (expr);         \
+    if (_r != E2ETTS_OK) return _r; \
+  } while (0)
+
+int ensure(e2etts_engine* e, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return E2ETTS_OK;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (b.p) {
+    HIPCHK(e, hipFree(b.p));
+    e->dev_bytes -= b.cap;
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = (bytes + 255) & ~size_t(255);
+  if (hipMalloc(&b.p, want) != hipSuccess) {
+    b.p = nullptr;
+    return e->fail(E2ETTS_ENOMEM, "hipMalloc(%zu bytes) failed", want);
+  }
+  b.cap = want;
+  e->dev_bytes += want;
+  return E2ETTS_OK;
+}
+
+template <typename T>
+T* ptr(DevBuf& b) { return reinterpret_cast<T*>(b.p); }
+
+int prof_class(e2etts_engine* e, const char* name) {
+  for (size_t i = 0; i < e->prof_stats.size(); ++i)
+    if (!strcmp(e->prof_stats[i].name, name)) return (int)i;
+  e2etts_kernel_stat s{};
+  snprintf(s.name, sizeof s.name, "%s", name);
+  e->prof_stats.push_back(s);
+  return (int)e->prof_stats.size() - 1;
+}
+
+hipEvent_t get_event(e2etts_engine* e) {
+  if (!e->ev_pool.empty()) {
+    hipEvent_t ev = e->ev_pool.back();
+    e->ev_pool.pop_back();
+    return ev;
+  }
+  hipEvent_t ev = nullptr;
+  (void)hipEventCreate(&ev);
+  return ev;
+}
+
+struct ProfScope {
+  e2etts_engine* e;
+  ProfRec rec{};
+  bool on;
+  ProfScope(e2etts_engine* e_, const char* name, double flops, double bytes) : e(e_), on(e_->prof_on) {
+    if (!on) return;
+    rec.cls = prof_class(e, name);
+    rec.flops = flops;
+    rec.bytes = bytes;
+    rec.start = get_event(e);
+    rec.stop = get_event(e);
+    (void)hipEventRecord(rec.start, e->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.stop, e->stream);
+    e->prof_recs.push_back(rec);
+  }
+};
+
+int prof_collect(e2etts_engine* e) {
+  if (e->prof_recs.empty()) return E2ETTS_OK;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (auto& r : e->prof_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      auto& s = e->prof_stats[r.cls];
+      s.launches += 1;
+      s.ms += ms;
+      s.flops += r.flops;
+      s.bytes += r.bytes;
+    }
+    e->ev_pool.push_back(r.start);
+    e->ev_pool.push_back(r.stop);
+  }
+  e->prof_recs.clear();
+  return E2ETTS_OK;
+}
+
+#define KCHK(e, expr)                                              \
+  do {                                                             \
+    const char* _m = (expr);                                       \
+    if (_m) return (e)->fail(E2ETTS_EINVAL, "%s", _m);             \
+  } while (0)
+
+const char* conv_cfg_name(int Cout) { return Cout > 64 ? "conv_gemm_128x128" : (Cout > 32 ? "conv_gemm_256x64" : "conv_gemm_256x32"); }
+
+// One conv / linear launch.  alg_scale < 1 when part of the packed weight is structural zeros
+// (the polyphase upsampler) so that the recorded FLOPs stay the algorithmic ones.
+int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
+  if (p.in_ld == 0) p.in_ld = p.Cin;
+  if (p.out_ld == 0) p.out_ld = p.Cout;
+  if (p.res && p.res_ld == 0) p.res_ld = p.Cout;
+  if (p.in_bs == 0) p.in_bs = (long long)p.T * p.in_ld;
+  if (p.out_bs == 0) p.out_bs = (long long)p.T * p.out_ld;
+  if (p.res && p.res_bs == 0) p.res_bs = (long long)p.T * p.res_ld;
+  ProfScope ps(e, conv_cfg_name(p.Cout), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
+  KCHK(e, launch_conv_gemm(p, e->stream));
+  return E2ETTS_OK;
+}
+
+int get_tensor(e2etts_engine* e, const std::string& name, uint64_t numel, const float** out) {
+  auto it = e->tensors.find(name);
+  if (it == e->tensors.end()) return e->fail(E2ETTS_EKEY, "weight blob has no tensor '%s'", name.c_str());
+  if (numel && it->second.second != numel)
+    return e->fail(E2ETTS_EINVAL, "tensor '%s' has %llu elements, expected %llu", name.c_str(),
+                   (unsigned long long)it->second.second, (unsigned long long)numel);
+  *out = it->second.first;
+  return E2ETTS_OK;
+}
+
+int bind_fft(e2etts_engine* e, const char* side, int layers, std::vector<FFTLayer>& v) {
+  const auto& c = e->cfg;
+  const uint64_t H = c.hidden, F = c.ffn_dim;
+  v.resize(layers);
+  for (int l = 0; l < layers; ++l) {
+    std::string p = std::string(side) + "." + std::to_string(l) + ".";
+    FFTLayer& f = v[l];
+    RET(get_tensor(e, p + "wqkv", 3 * H * H, &f.wqkv));
+    RET(get_tensor(e, p + "bqkv", 3 * H, &f.bqkv));
+    RET(get_tensor(e, p + "wo", H * H, &f.wo));
+    RET(get_tensor(e, p + "bo", H, &f.bo));
+    RET(get_tensor(e, p + "ln1.g", H, &f.ln1g));
+    RET(get_tensor(e, p + "ln1.b", H, &f.ln1b));
+    RET(get_tensor(e, p + "w1", F * c.ffn_k1 * H, &f.w1));
+    RET(get_tensor(e, p + "b1", F, &f.b1));
+    RET(get_tensor(e, p + "w2", H * F, &f.w2));
+    RET(get_tensor(e, p + "b2", H, &f.b2));
+    RET(get_tensor(e, p + "ln2.g", H, &f.ln2g));
+    RET(get_tensor(e, p + "ln2.b", H, &f.ln2b));
+  }
+  return E2ETTS_OK;
+}
+
+int bind_pred(e2etts_engine* e, const char* name, int layers, int kernel, int chans, int odim, bool alpha, Predictor& pr) {
+  const uint64_t H = e->cfg.hidden;
+  pr.layers.resize(layers);
+  pr.kernel = kernel;
+  pr.chans = chans;
+  pr.odim = odim;
+  for (int i = 0; i < layers; ++i) {
+    std::string p = std::string(name) + "." + std::to_string(i) + ".";
+    const uint64_t cin = i == 0 ? H : (uint64_t)chans;
+    RET(get_tensor(e, p + "w", (uint64_t)chans * kernel * cin, &pr.layers[i].w));
+    RET(get_tensor(e, p + "b", chans, &pr.layers[i].b));
+    RET(get_tensor(e, p + "g", chans, &pr.layers[i].g));
+    RET(get_tensor(e, p + "beta", chans, &pr.layers[i].beta));
+  }
+  RET(get_tensor(e, std::string(name) + ".lin.w", (uint64_t)odim * chans, &pr.lin_w));
+  RET(get_tensor(e, std::string(name) + ".lin.b", odim, &pr.lin_b));
+  if (alpha) RET(get_tensor(e, std::string(name) + ".alpha", 1, &pr.alpha));
+  return E2ETTS_OK;
+}
+
+int bind_all(e2etts_engine* e) {
+  const auto& c = e->cfg;
+  const uint64_t H = c.hidden;
+  RET(get_tensor(e, "enc.emb", (uint64_t)(c.n_symbols + 1) * H, &e->emb));
+  RET(get_tensor(e, "enc.pos", (uint64_t)(c.max_seq_len + 1) * H, &e->enc_pos));
+  RET(get_tensor(e, "dec.pos", (uint64_t)(c.max_seq_len + 1) * H, &e->dec_pos));
+  RET(get_tensor(e, "pos.regen", (uint64_t)c.pos_table_rows * H, &e->pos_regen));
+  RET(get_tensor(e, "spk.emb", (uint64_t)c.n_speakers * H, &e->spk_emb));
+  RET(bind_fft(e, "enc", c.enc_layers, e->enc));
+  RET(bind_fft(e, "dec", c.dec_layers, e->dec));
+  RET(bind_pred(e, "dur", c.dur_layers, c.dur_kernel, c.dur_chans, 1, false, e->dur));
+  RET(bind_pred(e, "pitch", c.var_layers, c.var_kernel, c.var_chans, 2, true, e->pitch));
+  RET(bind_pred(e, "energy", c.var_layers, c.var_kernel, c.var_chans, 1, true, e->energy));
+  {
+    auto it = e->tensors.find("var.pos");
+    if (it == e->tensors.end()) return e->fail(E2ETTS_EKEY, "weight blob has no tensor 'var.pos'");
+    if (it->second.second % H) return e->fail(E2ETTS_EINVAL, "var.pos size is not a multiple of hidden");
+    e->var_pos = it->second.first;
+    e->var_pos_rows = it->second.second / H;
+  }
+  RET(get_tensor(e, "pitch.emb", (uint64_t)c.n_bins * H, &e->pitch_emb));
+  RET(get_tensor(e, "energy.emb", (uint64_t)c.n_bins * H, &e->energy_emb));
+  RET(get_tensor(e, "energy.bins", (uint64_t)c.n_bins - 1, &e->energy_bins));
+  RET(get_tensor(e, "mel.w", (uint64_t)c.n_mel * H, &e->mel_lin.w));
+  RET(get_tensor(e, "mel.b", c.n_mel, &e->mel_lin.b));
+  e->postnet.resize(c.postnet_layers);
+  for (int i = 0; i < c.postnet_layers; ++i) {
+    const uint64_t cin = i == 0 ? c.n_mel : c.postnet_dim, cout = i == c.postnet_layers - 1 ? c.n_mel : c.postnet_dim;
+    std::string p = "post." + std::to_string(i) + ".";
+    RET(get_tensor(e, p + "w", cout * c.postnet_kernel * cin, &e->postnet[i].w));
+    RET(get_tensor(e, p + "b", cout, &e->postnet[i].b));
+  }
+  const uint64_t C0 = c.voc_init_ch;
+  RET(get_tensor(e, "voc.pre.w", C0 * 7 * c.n_mel, &e->voc_pre.w));
+  RET(get_tensor(e, "voc.pre.b", C0, &e->voc_pre.b));
+  e->voc_up.resize(c.voc_stages);
+  e->rb_c1.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
+  e->rb_c2.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
+  uint64_t ch = C0;
+  for (int i = 0; i < c.voc_stages; ++i) {
+    const uint64_t cin = ch, cout = ch / 2, s = c.voc_up_rate[i];
+    std::string p = "voc.up." + std::to_string(i) + ".";
+    RET(get_tensor(e, p + "w", s * cout * 3 * cin, &e->voc_up[i].w));
+    RET(get_tensor(e, p + "b", s * cout, &e->voc_up[i].b));
+    ch = cout;
+    for (int j = 0; j < c.voc_n_kernels; ++j) {
+      const int idx = i * c.voc_n_kernels + j;
+      const uint64_t k = c.voc_rb_kernel[j];
+      e->rb_c1[idx].resize(c.voc_n_dil);
+      e->rb_c2[idx].resize(c.voc_n_dil);
+      for (int m = 0; m < c.voc_n_dil; ++m) {
+        std::string q = "voc.rb." + std::to_string(idx) + ".";
+        RET(get_tensor(e, q + "c1." + std::to_string(m) + ".w", ch * k * ch, &e->rb_c1[idx][m].w));
+        RET(get_tensor(e, q + "c1." + std::to_string(m) + ".b", ch, &e->rb_c1[idx][m].b));
+        RET(get_tensor(e, q + "c2." + std::to_string(m) + ".w", ch * k * ch, &e->rb_c2[idx][m].w));
+        RET(get_tensor(e, q + "c2." + std::to_string(m) + ".b", ch, &e->rb_c2[idx][m].b));
+      }
+    }
+  }
+  RET(get_tensor(e, "voc.post.w", 7 * ch, &e->voc_post.w));
+  RET(get_tensor(e, "voc.post.b", 1, &e->voc_post.b));
+  return E2ETTS_OK;
+}
+
+// 6 x FFTBlock (reference U/blocks/transformer.py:178-189), in place on x ([B, N, H]); lens32: device [B]
+int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N) {
+  const auto& c = e->cfg;
+  const int H = c.hidden, F = c.ffn_dim;
+  float* qkv = ptr<float>(e->qkv);
+  float* att = ptr<float>(e->att);
+  float* tmp = ptr<float>(e->tmp);
+  float* hid = ptr<float>(e->hid);
+  for (const FFTLayer& f : layers) {
+    ConvParams p;
+    p.B = B; p.T = N;
+    // q | k | v projections as one GEMM (U/blocks/transformer.py:220-222)
+    p.in = x; p.w = f.wqkv; p.bias = f.bqkv; p.out = qkv; p.Cin = H; p.Cout = 3 * H;
+    RET(conv(e, p));
+    {
+      const double fl = 4.0 * B * c.n_head * (double)N * N * (H / c.n_head);
+      ProfScope ps(e, "attention", fl, 4.0 * 4.0 * B * N * H);
+      KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, e->stream));
+    }
+    // fc + residual (:238-239), LayerNorm eps 1e-5, masked_fill (:182-183)
+    p = ConvParams(); p.B = B; p.T = N;
+    p.in = att; p.w = f.wo; p.bias = f.bo; p.res = x; p.out = tmp; p.Cin = H; p.Cout = H;
+    RET(conv(e, p));
+    {
+      ProfScope ps(e, "layernorm", 0, 8.0 * B * N * H);
+      KCHK(e, launch_layernorm(tmp, xalt, f.ln1g, f.ln1b, lens, B, N, H, 1e-5f, e->stream));
+    }
+    // conv k9 + ReLU, conv k1 + residual, LayerNorm, masked_fill (:289-297, :185-187)
+    p = ConvParams(); p.B = B; p.T = N;
+    p.in = xalt; p.w = f.w1; p.bias = f.b1; p.out = hid; p.Cin = H; p.Cout = F; p.KW = c.ffn_k1; p.pad = (c.ffn_k1 - 1) / 2;
+    p.act = ACT_RELU;
+    RET(conv(e, p));
+    p = ConvParams(); p.B = B; p.T = N;
+    p.in = hid; p.w = f.w2; p.bias = f.b2; p.res = xalt; p.out = tmp; p.Cin = F; p.Cout = H;
+    RET(conv(e, p));
+    {
+      ProfScope ps(e, "layernorm", 0, 8.0 * B * N * H);
+      KCHK(e, launch_layernorm(tmp, x, f.ln2g, f.ln2b, lens, B, N, H, 1e-5f, e->stream));
+    }
+  }
+  return E2ETTS_OK;
+}
+
+// conv -> ReLU -> channel LayerNorm(eps 1e-12) [-> x (1 - mask)] stack + small Linear
+// (reference DurationPredictor U/layers.py:410-420, VariancePredictor :499-503)
+int predictor(e2etts_engine* e, const Predictor& pr, const float* x, float* out, const int32_t* mask_lens, int B, int L) {
+  const int H = e->cfg.hidden;
+  float* a = ptr<float>(e->p1);  // conv output
+  float* b = ptr<float>(e->p2);  // LayerNorm output = next layer's input
+  const float* in = x;
+  int cin = H;
+  for (const PredLayer& l : pr.layers) {
+    ConvParams p;
+    p.B = B; p.T = L; p.in = in; p.w = l.w; p.bias = l.b; p.out = a; p.Cin = cin; p.Cout = pr.chans;
+    p.KW = pr.kernel; p.pad = (pr.kernel - 1) / 2; p.act = ACT_RELU;
+    RET(conv(e, p));
+    {
+      ProfScope ps(e, "layernorm", 0, 8.0 * B * L * pr.chans);
+      KCHK(e, launch_layernorm(a, b, l.g, l.beta, mask_lens, B, L, pr.chans, 1e-12f, e->stream));
+    }
+    in = b;
+    cin = pr.chans;
+  }
+  {
+    ProfScope ps(e, "misc", 0, 0);
+    KCHK(e, launch_rowdot(in, pr.lin_w, pr.lin_b, out, mask_lens, B, L, pr.chans, pr.odim, e->stream));
+  }
+  return E2ETTS_OK;
+}
+
+bool is_device_pointer(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice;
+}
+
+int copy_in(e2etts_engine* e, void* dst, const void* src, size_t bytes) {
+  HIPCHK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, e->stream));
+  return E2ETTS_OK;
+}
+
+int copy_out(e2etts_engine* e, void* dst, const void* src, size_t bytes) {
+  HIPCHK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, e->stream));
+  return E2ETTS_OK;
+}
+
+__global__ void lens_to_i32_kernel(const int64_t* in, int32_t* out, int B, int L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) {
+    long long v = in[i];
+    out[i] = (int32_t)(v < 0 ? 0 : (v > L ? L : v));
+  }
+}
+
+int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int B, int L, const int64_t* speaker,
+                  int n_spk_ids, float d_control, float p_control, float e_control) {
+  const auto& c = e->cfg;
+  if (!e->loaded) return e->fail(E2ETTS_ESTATE, "weights not loaded");
+  if (!ids || !lens || !speaker) return e->fail(E2ETTS_EINVAL, "ids / lens / speaker must not be NULL");
+  if (B <= 0 || L <= 0) return e->fail(E2ETTS_EINVAL, "B and L must be positive (got B=%d L=%d)", B, L);
+  if (n_spk_ids != 1 && n_spk_ids != B) return e->fail(E2ETTS_EINVAL, "speaker must hold 1 or B ids");
+  if (L > c.max_seq_len && L > c.pos_table_rows)
+    return e->fail(E2ETTS_EINVAL, "L=%d exceeds the shipped position table (%d rows)", L, c.pos_table_rows);
+  if ((uint64_t)L + 1 > e->var_pos_rows)
+    return e->fail(E2ETTS_EINVAL, "L=%d exceeds the variance-predictor position table (%llu rows)", L,
+                   (unsigned long long)e->var_pos_rows);
+  // host-side validation when the caller's buffers are host memory (KeyError / IndexError in the reference)
+  if (!is_device_pointer(ids) && !is_device_pointer(lens)) {
+    for (int b = 0; b < B; ++b)
+      if (lens[b] < 1 || lens[b] > L) return e->fail(E2ETTS_EINVAL, "lens[%d]=%lld outside [1, %d]", b, (long long)lens[b], L);
+    for (long long i = 0; i < (long long)B * L; ++i)
+      if (ids[i] < 0 || ids[i] > c.n_symbols) return e->fail(E2ETTS_EINVAL, "symbol id %lld out of range", (long long)ids[i]);
+  }
+  if (!is_device_pointer(speaker))
+    for (int i = 0; i < n_spk_ids; ++i)
+      if (speaker[i] < 0 || speaker[i] >= c.n_speakers) return e->fail(E2ETTS_EINVAL, "speaker id %lld out of range", (long long)speaker[i]);
+
+  const int H = c.hidden, F = c.ffn_dim;
+  const size_t BL = (size_t)B * L;
+  RET(ensure(e, e->ids, BL * 8));
+  RET(ensure(e, e->lens64, (size_t)B * 8));
+  RET(ensure(e, e->lens32, (size_t)B * 4));
+  RET(ensure(e, e->spk, (size_t)B * 8));
+  RET(ensure(e, e->xa, BL * H * 4));
+  RET(ensure(e, e->xb, BL * H * 4));
+  RET(ensure(e, e->xs, BL * H * 4));
+  RET(ensure(e, e->xp, BL * H * 4));
+  RET(ensure(e, e->tmp, BL * H * 4));
+  RET(ensure(e, e->qkv, BL * 3 * H * 4));
+  RET(ensure(e, e->att, BL * H * 4));
+  RET(ensure(e, e->hid, BL * F * 4));
+  const size_t pc = std::max(c.dur_chans, c.var_chans);
+  RET(ensure(e, e->p1, BL * pc * 4));
+  RET(ensure(e, e->p2, BL * pc * 4));
+  RET(ensure(e, e->logd, BL * 4));
+  RET(ensure(e, e->durf, BL * 4));
+  RET(ensure(e, e->cum, BL * 4));
+  RET(ensure(e, e->mel64, (size_t)B * 8));
+  RET(ensure(e, e->mel32, (size_t)B * 4));
+  RET(ensure(e, e->posbuf, BL * 4));
+  RET(ensure(e, e->ppred, BL * 2 * 4));
+  RET(ensure(e, e->epred, BL * 4));
+  RET(ensure(e, e->pidx, BL * 4));
+  RET(ensure(e, e->eidx, BL * 4));
+  RET(ensure(e, e->encout, BL * H * 4));
+
+  e->have_acoustic = false;
+  RET(copy_in(e, e->ids.p, ids, BL * 8));
+  RET(copy_in(e, e->lens64.p, lens, (size_t)B * 8));
+  RET(copy_in(e, e->spk.p, speaker, (size_t)n_spk_ids * 8));
+  hipLaunchKernelGGL(lens_to_i32_kernel, dim3((B + 63) / 64), dim3(64), 0, e->stream, ptr<int64_t>(e->lens64),
+                     ptr<int32_t>(e->lens32), B, L);
+  const int32_t* tl = ptr<int32_t>(e->lens32);
+
+  // Encoder (U/blocks/transformer.py:58-86): embedding + position table, 6 x FFTBlock
+  const float* pos = L > c.max_seq_len ? e->pos_regen : e->enc_pos;  // eval-time regeneration branch (:68-73)
+  float* x = ptr<float>(e->xa);
+  {
+    ProfScope ps(e, "misc", 0, 0);
+    KCHK(e, launch_embed(ptr<int64_t>(e->ids), e->emb, pos, x, B, L, H, c.n_symbols + 1, e->stream));
+  }
+  RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L));
+  HIPCHK(e, hipMemcpyAsync(e->encout.p, x, BL * H * 4, hipMemcpyDeviceToDevice, e->stream));
+
+  // Variance adaptor, inference branch (U/layers.py:195-258)
+  float* xs = ptr<float>(e->xs);
+  HIPCHK(e, hipMemcpyAsync(xs, x, BL * H * 4, hipMemcpyDeviceToDevice, e->stream));
+  {
+    ProfScope ps(e, "misc", 0, 0);
+    KCHK(e, launch_add_speaker(xs, e->spk_emb, ptr<int64_t>(e->spk), n_spk_ids, c.n_speakers, B, L, H, e->stream));
+  }
+  RET(predictor(e, e->dur, xs, ptr<float>(e->logd), tl, B, L));
+  {
+    ProfScope ps(e, "misc", 0, 0);
+    KCHK(e, launch_duration(ptr<float>(e->logd), d_control, ptr<float>(e->durf), ptr<int32_t>(e->cum),
+                            ptr<int64_t>(e->mel64), ptr<int32_t>(e->mel32), B, L, e->stream));
+  }
+  HIPCHK(e, hipMemcpyAsync(e->h_mel, e->mel64.p, (size_t)B * 8, hipMemcpyDeviceToHost, e->stream));
+  hipEvent_t mel_ready = get_event(e);
+  HIPCHK(e, hipEventRecord(mel_ready, e->stream));
+  // pitch / energy predictors run while the mel lengths travel to the host
+  float* xp = ptr<float>(e->xp);
+  {
+    ProfScope ps(e, "misc", 0, 0);
+    KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->pitch.alpha, xp, B, L, H, e->stream));
+  }
+  RET(predictor(e, e->pitch, xp, ptr<float>(e->ppred), nullptr, B, L));
+  {
+    ProfScope ps(e, "misc", 0, 0);
+    KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->energy.alpha, xp, B, L, H, e->stream));
+  }
+  RET(predictor(e, e->energy, xp, ptr<float>(e->epred), nullptr, B, L));
+  {
+    ProfScope ps(e, "misc", 0, 0);
+    KCHK(e, launch_variance_embed(xs, ptr<float>(e->ppred), ptr<float>(e->epred), p_control, e_control, c.f0_mean, c.f0_std,
+                                  e->energy_bins, c.n_bins, e->pitch_emb, e->energy_emb, ptr<int32_t>(e->pidx),
+                                  ptr<int32_t>(e->eidx), B, L, H, e->stream));
+  }
+  // the one host synchronisation of the acoustic model: T = max(mel_lens) sizes everything downstream
+  HIPCHK(e, hipEventSynchronize(mel_ready));
+  e->ev_pool.push_back(mel_ready);
+  long long T = 0;
+  for (int b = 0; b < B; ++b) T = std::max<long long>(T, e->h_mel[b]);
+  if (T <= 0) return e->fail(E2ETTS_EINVAL, "every predicted duration is zero: nothing to synthesise");
+  if (T > c.max_seq_len && T > c.pos_table_rows)
+    return e->fail(E2ETTS_EINVAL, "T=%lld exceeds the shipped position table (%d rows)", T, c.pos_table_rows);
+  if (T > (1 << 20)) return e->fail(E2ETTS_EINVAL, "T=%lld is unreasonably large", T);
+  const size_t BT = (size_t)B * T;
+  RET(ensure(e, e->dx, BT * H * 4));
+  RET(ensure(e, e->dxb, BT * H * 4));
+  RET(ensure(e, e->tmp, BT * H * 4));
+  RET(ensure(e, e->qkv, BT * 3 * H * 4));
+  RET(ensure(e, e->att, BT * H * 4));
+  RET(ensure(e, e->hid, BT * F * 4));
+  RET(ensure(e, e->mel, BT * c.n_mel * 4));
+  RET(ensure(e, e->melpost, BT * c.n_mel * 4));
+  RET(ensure(e, e->pn1, BT * c.postnet_dim * 4));
+  RET(ensure(e, e->pn2, BT * c.postnet_dim * 4));
+
+  // Length regulator (U/layers.py:423-457) fused with the decoder's position add (U/blocks/transformer.py:138-153)
+  const float* dpos = T > c.max_seq_len ? e->pos_regen : e->dec_pos;
+  float* dx = ptr<float>(e->dx);
+  const int32_t* ml = ptr<int32_t>(e->mel32);
+  {
+    ProfScope ps(e, "misc", 0, 0);
+    KCHK(e, launch_length_regulate(xs, ptr<int32_t>(e->cum), ml, dpos, dx, B, L, (int)T, H, e->stream));
+  }
+  RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T));
+  // mel_linear (U/model.py:186)
+  ConvParams p;
+  p.B = B; p.T = (int)T; p.in = dx; p.w = e->mel_lin.w; p.bias = e->mel_lin.b; p.out = ptr<float>(e->mel); p.Cin = H; p.Cout = c.n_mel;
+  RET(conv(e, p));
+  // Postnet (U/layers.py:556-563; BatchNorm folded at pack time) + residual (U/model.py:188); unmasked
+  const float* pin = ptr<float>(e->mel);
+  int cin = c.n_mel;
+  float* bufs[2] = {ptr<float>(e->pn1), ptr<float>(e->pn2)};
+  for (int i = 0; i < c.postnet_layers; ++i) {
+    const bool last = i == c.postnet_layers - 1;
+    p = ConvParams();
+    p.B = B; p.T = (int)T; p.in = pin; p.w = e->postnet[i].w; p.bias = e->postnet[i].b; p.Cin = cin;
+    p.Cout = last ? c.n_mel : c.postnet_dim; p.KW = c.postnet_kernel; p.pad = (c.postnet_kernel - 1) / 2;
+    if (last) { p.out = ptr<float>(e->melpost); p.res = ptr<float>(e->mel); }
+    else { p.out = bufs[i & 1]; p.act = ACT_TANH; }
+    RET(conv(e, p));
+    pin = p.out;
+    cin = p.Cout;
+  }
+  e->last_B = B; e->last_L = L; e->last_T = (int)T;
+  e->have_acoustic = true;
+  return E2ETTS_OK;
+}
+
+// HifiGan.forward (V/generator.py:37-53) on channels-last mel [B, T, n_mel] already in HBM
+int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want_wav, bool want_pcm) {
+  const auto& c = e->cfg;
+  if (!e->loaded) return e->fail(E2ETTS_ESTATE, "weights not loaded");
+  if (B <= 0 || T <= 0) return e->fail(E2ETTS_EINVAL, "B and T must be positive");
+  // largest activation of any stage, in floats per utterance
+  long long len = T, ch = c.voc_init_ch;
+  long long maxv = len * ch;
+  for (int i = 0; i < c.voc_stages; ++i) {
+    len *= c.voc_up_rate[i];
+    ch /= 2;
+    maxv = std::max(maxv, len * ch);
+  }
+  if (ch < 4 || (ch % 4)) return e->fail(E2ETTS_EINVAL, "final vocoder width %lld must be a positive multiple of 4", ch);
+  const long long nsamp = len;
+  if (nsamp != (long long)T * c.hop_length) return e->fail(E2ETTS_EINVAL, "upsample product != hop_length");
+  const size_t vb = (size_t)B * maxv * 4;
+  RET(ensure(e, e->v0, vb));
+  RET(ensure(e, e->v1, vb));
+  RET(ensure(e, e->v2, vb));
+  RET(ensure(e, e->v3, vb));
+  RET(ensure(e, e->wav, (size_t)B * nsamp * 4));
+  RET(ensure(e, e->pcm, (size_t)B * nsamp * 2));
+  e->have_wav = false;
+  float *S = ptr<float>(e->v0), *XU = ptr<float>(e->v1), *T1 = ptr<float>(e->v2), *CUR = ptr<float>(e->v3);
+
+  ConvParams p;
+  p.B = B; p.T = T; p.in = mel_btc; p.w = e->voc_pre.w; p.bias = e->voc_pre.b; p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
+  p.KW = 7; p.pad = 3;
+  RET(conv(e, p));
+  long long n = T;
+  ch = c.voc_init_ch;
+  for (int i = 0; i < c.voc_stages; ++i) {
+    const int s = c.voc_up_rate[i];
+    const int co = (int)ch / 2;
+    // leaky_relu(0.1) -> ConvTranspose1d(k = 2s, stride s, pad s/2)  (V/generator.py:40-41) as a 3-tap convolution
+    // with s * co output channels: row q of the [n, s*co] result IS rows q*s .. q*s+s-1 of the [n*s, co] signal.
+    p = ConvParams();
+    p.B = B; p.T = (int)n; p.in = S; p.w = e->voc_up[i].w; p.bias = e->voc_up[i].b; p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
+    p.KW = 3; p.pad = 1; p.in_slope = 0.1f;
+    RET(conv(e, p, 2.0 / 3.0));
+    n *= s;
+    ch = co;
+    if (n > 0x7fffffffLL / 2) return e->fail(E2ETTS_EINVAL, "utterance too long");
+    for (int j = 0; j < c.voc_n_kernels; ++j) {
+      const int idx = i * c.voc_n_kernels + j;
+      const int k = c.voc_rb_kernel[j];
+      const float* cur = XU;
+      for (int m = 0; m < c.voc_n_dil; ++m) {
+        const int d = c.voc_rb_dil[j][m];
+        // xt = c1(lrelu(x)); the lrelu that feeds c2 is applied here, in c1's epilogue (V/layers.py:35-38)
+        p = ConvParams();
+        p.B = B; p.T = (int)n; p.in = cur; p.w = e->rb_c1[idx][m].w; p.bias = e->rb_c1[idx][m].b; p.out = T1; p.Cin = co; p.Cout = co;
+        p.KW = k; p.dil = d; p.pad = (k * d - d) / 2; p.in_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f;
+        RET(conv(e, p));
+        // x = c2(xt) + x (:38-39); the last pair adds into the stage sum, and the last ResBlock divides by num_kernels
+        // (V/generator.py:44-48)
+        const bool last = m == c.voc_n_dil - 1;
+        p = ConvParams();
+        p.B = B; p.T = (int)n; p.in = T1; p.w = e->rb_c2[idx][m].w; p.bias = e->rb_c2[idx][m].b; p.res = cur; p.Cin = co; p.Cout = co;
+        p.KW = k; p.dil = 1; p.pad = (k - 1) / 2;
+        if (last) {
+          p.out = S;
+          p.accumulate = j > 0;
+          if (j == c.voc_n_kernels - 1) p.out_div = (float)c.voc_n_kernels;
+        } else {
+          p.out = CUR;
+        }
+        RET(conv(e, p));
+        cur = CUR;
+      }
+    }
+  }
+  {
+    ProfScope ps(e, "conv_post", 2.0 * B * (double)n * 7 * ch, (double)B * n * (ch * 4.0 + 6.0));
+    KCHK(e, launch_conv_post(S, e->voc_post.w, e->voc_post.b, ptr<float>(e->wav), ptr<int16_t>(e->pcm), B, n, (int)ch, 7, e->stream));
+  }
+  (void)want_wav; (void)want_pcm;
+  e->voc_B = B; e->voc_T = T;
+  e->have_wav = true;
+  return E2ETTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* e2etts_version(void) { return "e2etts-hip 0.1 (gfx950, fp32 MFMA)"; }
+
+const char* e2etts_last_error(const e2etts_engine* engine) { return engine ? engine->err.c_str() : g_create_error.c_str(); }
+
+int e2etts_create(int device_id, const e2etts_config* cfg, e2etts_engine** out) {
+  if (!cfg || !out) { g_create_error = "cfg / out must not be NULL"; return E2ETTS_EINVAL; }
+  *out = nullptr;
+  const e2etts_config& c = *cfg;
+  auto bad = [&](const char* m) { g_create_error = m; return E2ETTS_EINVAL; };
+  if (c.hidden <= 0 || c.hidden % 4 || c.n_head <= 0 || c.hidden % c.n_head) return bad("hidden must be a positive multiple of 4 and of n_head");
+  if (c.n_mel <= 0 || c.n_mel % 4) return bad("n_mel must be a positive multiple of 4");
+  if (c.ffn_dim % 4 || c.dur_chans % 4 || c.var_chans % 4 || c.postnet_dim % 4) return bad("channel counts must be multiples of 4");
+  if (c.ffn_k2 != 1 || !(c.ffn_k1 & 1)) return bad("FFN kernels must be (odd, 1)");
+  if (c.voc_stages <= 0 || c.voc_stages > E2ETTS_MAX_STAGES || c.voc_n_kernels <= 0 || c.voc_n_kernels > E2ETTS_MAX_RB_KERNELS ||
+      c.voc_n_dil <= 0 || c.voc_n_dil > E2ETTS_MAX_DILATIONS) return bad("vocoder stage / kernel / dilation counts out of range");
+  for (int i = 0; i < c.voc_stages; ++i)
+    if (c.voc_up_kernel[i] != 2 * c.voc_up_rate[i] || (c.voc_up_rate[i] & 1)) return bad("upsample kernel must be 2 x rate, rate even");
+  if ((c.voc_init_ch >> c.voc_stages) < 4 || (c.voc_init_ch % (4 << c.voc_stages))) return bad("upsample_initial_channel too small for the stage count");
+  if (c.n_bins != 256) return bad("n_bins must be 256");
+  if (c.pos_table_rows < c.max_seq_len + 1) return bad("pos_table_rows must cover max_seq_len + 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device visible: the e2etts engine has no CPU fallback";
+    return E2ETTS_EHIP;
+  }
+  if (device_id < 0 || device_id >= ndev) return bad("device_id out of range");
+  if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return E2ETTS_EHIP; }
+  e2etts_engine* e = new e2etts_engine();
+  e->cfg = c;
+  e->device = device_id;
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_mel, 4096 * sizeof(int64_t)) != hipSuccess) {
+    g_create_error = "stream / pinned buffer creation failed";
+    delete e;
+    return E2ETTS_EHIP;
+  }
+  *out = e;
+  return E2ETTS_OK;
+}
+
+void e2etts_destroy(e2etts_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  DevBuf* bufs[] = {&e->blob, &e->ids, &e->lens64, &e->lens32, &e->spk, &e->xa, &e->xb, &e->xs, &e->xp, &e->tmp, &e->qkv, &e->att,
+                    &e->hid, &e->p1, &e->p2, &e->logd, &e->durf, &e->cum, &e->mel64, &e->mel32, &e->posbuf, &e->ppred, &e->epred,
+                    &e->pidx, &e->eidx, &e->dx, &e->dxb, &e->mel, &e->melpost, &e->pn1, &e->pn2, &e->encout, &e->melin, &e->v0,
+                    &e->v1, &e->v2, &e->v3, &e->wav, &e->pcm};
+  for (DevBuf* b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+  for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+  if (e->h_mel) (void)hipHostFree(e->h_mel);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!blob || nbytes < sizeof(BlobHeader)) return e->fail(E2ETTS_EINVAL, "weight blob too small");
+  BlobHeader h;
+  HIPCHK(e, hipMemcpy(&h, blob, sizeof h, hipMemcpyDefault));
+  if (memcmp(h.magic, "E2ETTSW1", 8) || h.version != 1) return e->fail(E2ETTS_EINVAL, "not an e2etts weight blob (bad magic / version)");
+  if (h.total_bytes != nbytes) return e->fail(E2ETTS_EINVAL, "blob size %zu != header total %llu", nbytes, (unsigned long long)h.total_bytes);
+  const size_t dir_bytes = (size_t)h.n_entries * sizeof(BlobEntry);
+  if (h.n_entries > 100000 || sizeof h + dir_bytes > h.data_offset || h.data_offset > nbytes || (h.data_offset & 255))
+    return e->fail(E2ETTS_EINVAL, "corrupt blob directory");
+  std::vector<BlobEntry> dir(h.n_entries);
+  HIPCHK(e, hipMemcpy(dir.data(), (const char*)blob + sizeof h, dir_bytes, hipMemcpyDefault));
+  e->loaded = false;
+  RET(ensure(e, e->blob, nbytes));
+  HIPCHK(e, hipMemcpyAsync(e->blob.p, blob, nbytes, hipMemcpyDefault, e->stream));
+  e->tensors.clear();
+  for (auto& en : dir) {
+    en.name[sizeof en.name - 1] = 0;
+    if ((en.offset & 255) || en.offset < h.data_offset || en.offset + en.numel * 4 > nbytes)
+      return e->fail(E2ETTS_EINVAL, "tensor '%s' lies outside the blob", en.name);
+    e->tensors[en.name] = {reinterpret_cast<const float*>((const char*)e->blob.p + en.offset), en.numel};
+  }
+  RET(bind_all(e));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->loaded = true;
+  return E2ETTS_OK;
+}
+
+int e2etts_acoustic(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int B, int L, const int64_t* speaker,
+                    int n_spk_ids, float d_control, float p_control, float e_control, float* dur_out, int64_t* mel_lens_out,
+                    int* T_out, int32_t* pitch_idx_out, int32_t* energy_idx_out, float* log_dur_out, float* pitch_pred_out,
+                    float* energy_pred_out) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (B > 4096) return e->fail(E2ETTS_EINVAL, "B > 4096");
+  RET(acoustic_impl(e, ids, lens, B, L, speaker, n_spk_ids, d_control, p_control, e_control));
+  const size_t BL = (size_t)B * L;
+  if (dur_out) RET(copy_out(e, dur_out, e->durf.p, BL * 4));
+  if (mel_lens_out) RET(copy_out(e, mel_lens_out, e->mel64.p, (size_t)B * 8));
+  if (pitch_idx_out) RET(copy_out(e, pitch_idx_out, e->pidx.p, BL * 4));
+  if (energy_idx_out) RET(copy_out(e, energy_idx_out, e->eidx.p, BL * 4));
+  if (log_dur_out) RET(copy_out(e, log_dur_out, e->logd.p, BL * 4));
+  if (pitch_pred_out) RET(copy_out(e, pitch_pred_out, e->ppred.p, BL * 8));
+  if (energy_pred_out) RET(copy_out(e, energy_pred_out, e->epred.p, BL * 4));
+  if (T_out) *T_out = e->last_T;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+int e2etts_fetch_mel(e2etts_engine* e, float* mel, float* mel_post) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->have_acoustic) return e->fail(E2ETTS_ESTATE, "no acoustic result resident");
+  const size_t n = (size_t)e->last_B * e->last_T * e->cfg.n_mel * 4;
+  if (mel) RET(copy_out(e, mel, e->mel.p, n));
+  if (mel_post) RET(copy_out(e, mel_post, e->melpost.p, n));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+int e2etts_fetch_tap(e2etts_engine* e, const char* which, float* out, size_t n_floats) {
+  if (!e || !which || !out) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->have_acoustic) return e->fail(E2ETTS_ESTATE, "no acoustic result resident");
+  const void* src = nullptr;
+  size_t n = 0;
+  if (!strcmp(which, "enc_out")) { src = e->encout.p; n = (size_t)e->last_B * e->last_L * e->cfg.hidden; }
+  else if (!strcmp(which, "dec_out")) { src = e->dx.p; n = (size_t)e->last_B * e->last_T * e->cfg.hidden; }
+  else return e->fail(E2ETTS_EKEY, "unknown tap '%s'", which);
+  if (n_floats != n) return e->fail(E2ETTS_EINVAL, "tap '%s' holds %zu floats, caller asked for %zu", which, n, n_floats);
+  RET(copy_out(e, out, src, n * 4));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+static int vocoder_entry(e2etts_engine* e, const float* mel, bool channels_first, int B, int T, float* wav_out, int16_t* pcm_out) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  const float* src = nullptr;
+  if (!mel) {
+    if (!e->have_acoustic) return e->fail(E2ETTS_ESTATE, "mel == NULL but no acoustic result is resident");
+    if (B != e->last_B || T != e->last_T) return e->fail(E2ETTS_EINVAL, "resident mel is [%d, %d, n_mel], caller said [%d, %d]", e->last_B, e->last_T, B, T);
+    src = ptr<float>(e->melpost);
+  } else {
+    if (B <= 0 || T <= 0) return e->fail(E2ETTS_EINVAL, "B and T must be positive");
+    const size_t n = (size_t)B * T * e->cfg.n_mel * 4;
+    RET(ensure(e, e->melin, 2 * n));
+    float* stage = ptr<float>(e->melin);
+    float* btc = stage + (size_t)B * T * e->cfg.n_mel;
+    if (channels_first) {
+      RET(copy_in(e, stage, mel, n));
+      KCHK(e, launch_transpose_bct_btc(stage, btc, B, e->cfg.n_mel, T, e->stream));
+    } else {
+      RET(copy_in(e, btc, mel, n));
+    }
+    src = btc;
+  }
+  RET(vocoder_impl(e, src, B, T, wav_out != nullptr, pcm_out != nullptr));
+  const size_t ns = (size_t)B * T * e->cfg.hop_length;
+  if (wav_out) RET(copy_out(e, wav_out, e->wav.p, ns * 4));
+  if (pcm_out) RET(copy_out(e, pcm_out, e->pcm.p, ns * 2));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+int e2etts_vocoder(e2etts_engine* e, const float* mel_bct, int B, int T, float* wav_out, int16_t* pcm_out) {
+  return vocoder_entry(e, mel_bct, true, B, T, wav_out, pcm_out);
+}
+
+int e2etts_vocoder_btc(e2etts_engine* e, const float* mel_btc, int B, int T, float* wav_out, int16_t* pcm_out) {
+  return vocoder_entry(e, mel_btc, false, B, T, wav_out, pcm_out);
+}
+
+int e2etts_synthesize(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int B, int L, const int64_t* speaker, int n_spk_ids,
+                      float d_control, float p_control, float e_control, int16_t* pcm_out, size_t pcm_capacity,
+                      int64_t* mel_lens_out, int* T_out) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (B > 4096) return e->fail(E2ETTS_EINVAL, "B > 4096");
+  RET(acoustic_impl(e, ids, lens, B, L, speaker, n_spk_ids, d_control, p_control, e_control));
+  if (T_out) *T_out = e->last_T;
+  RET(vocoder_impl(e, ptr<float>(e->melpost), B, e->last_T, false, true));
+  if (mel_lens_out) RET(copy_out(e, mel_lens_out, e->mel64.p, (size_t)B * 8));
+  const size_t ns = (size_t)B * e->last_T * e->cfg.hop_length;
+  if (pcm_out) {
+    if (pcm_capacity < ns) {
+      HIPCHK(e, hipStreamSynchronize(e->stream));
+      return e->fail(E2ETTS_EINVAL, "pcm buffer holds %zu samples, result has %zu (fetch it with e2etts_fetch_pcm)", pcm_capacity, ns);
+    }
+    RET(copy_out(e, pcm_out, e->pcm.p, ns * 2));
+  }
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+int e2etts_fetch_pcm(e2etts_engine* e, int16_t* pcm_out, size_t capacity) {
+  if (!e || !pcm_out) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->have_wav) return e->fail(E2ETTS_ESTATE, "no vocoder result resident");
+  const size_t ns = (size_t)e->voc_B * e->voc_T * e->cfg.hop_length;
+  if (capacity < ns) return e->fail(E2ETTS_EINVAL, "buffer holds %zu samples, result has %zu", capacity, ns);
+  RET(copy_out(e, pcm_out, e->pcm.p, ns * 2));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+int e2etts_fetch_wav(e2etts_engine* e, float* wav_out, size_t capacity) {
+  if (!e || !wav_out) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->have_wav) return e->fail(E2ETTS_ESTATE, "no vocoder result resident");
+  const size_t ns = (size_t)e->voc_B * e->voc_T * e->cfg.hop_length;
+  if (capacity < ns) return e->fail(E2ETTS_EINVAL, "buffer holds %zu samples, result has %zu", capacity, ns);
+  RET(copy_out(e, wav_out, e->wav.p, ns * 4));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+int e2etts_profile_enable(e2etts_engine* e, int enable) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  RET(prof_collect(e));
+  e->prof_stats.clear();
+  e->prof_on = enable != 0;
+  return E2ETTS_OK;
+}
+
+int e2etts_profile_read(e2etts_engine* e, e2etts_kernel_stat* out, int cap) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  RET(prof_collect(e));
+  const int n = (int)e->prof_stats.size();
+  for (int i = 0; i < n && i < cap && out; ++i) out[i] = e->prof_stats[i];
+  return n;
+}
+
+size_t e2etts_device_bytes(const e2etts_engine* e) { return e ? e->dev_bytes : 0; }
+
+void* e2etts_stream(e2etts_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int e2etts_sync(e2etts_engine* e) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Launch wrappers of the hand-written gfx950 kernels.  Every wrapper validates its shapes on the host
+// (returning a message instead of launching) because an out-of-bounds access on this pool can reset the
+// whole node; kernels themselves bounds-check every global access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace e2etts {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3 };
+
+// out[b, t, n] = epilogue( sum_{j < KW} sum_{c < Cin} f(in[b, t - pad + j*dil, c]) * w[n, j*Cin + c] )
+// "same" 1-D convolution as an implicit GEMM on the fp32 MFMA (M = time, N = Cout, K = KW*Cin);
+// KW == 1 is a plain Linear.  Rows outside [0, T) read as zero (zero padding).
+struct ConvParams {
+  const float* in = nullptr;     // [B, T, Cin]  (row stride in_ld, batch stride in_bs)
+  const float* w = nullptr;      // [Cout, KW*Cin] tap-major
+  const float* bias = nullptr;   // [Cout] or null
+  const float* res = nullptr;    // optional residual, same indexing as out
+  float* out = nullptr;          // [B, T, Cout]
+  const int32_t* lens = nullptr; // optional [B]: output rows t >= lens[b] are written as 0
+  int B = 0, T = 0, Cin = 0, Cout = 0, KW = 1, dil = 1, pad = 0;
+  long long in_bs = 0, out_bs = 0, res_bs = 0;
+  int in_ld = 0, out_ld = 0, res_ld = 0;
+  float in_slope = 1.0f;  // leaky-ReLU slope applied to the input while staging (1 = identity)
+  int act = ACT_NONE;     // applied after bias
+  float act_slope = 0.0f;
+  int accumulate = 0;     // out = out_old + value
+  float out_div = 1.0f;   // then value / out_div
+};
+// returns nullptr on success, else a static error string
+const char* launch_conv_gemm(const ConvParams& p, hipStream_t s);
+double conv_gemm_flops(const ConvParams& p);
+double conv_gemm_bytes(const ConvParams& p);
+
+// Fused masked self-attention on the packed QKV buffer of one FFT block.
+// qkv [B, N, 3H] (q | k | v, head h at columns h*dk .. (h+1)*dk of each third); keys >= lens[b] masked (-inf);
+// out [B, N, H]; query rows >= lens[b] are written as 0 (they are zeroed after the LayerNorm anyway).
+const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head,
+                             hipStream_t s);
+
+// y[row, :] = LayerNorm(x[row, :]) * gamma + beta; rows t >= lens[b] -> 0 when lens != null (C <= 1024, C % 4 == 0)
+const char* launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, const int32_t* lens,
+                             int B, int N, int C, float eps, hipStream_t s);
+
+// x[b, l, :] = emb[ids[b, l], :] + pos[l, :]
+const char* launch_embed(const int64_t* ids, const float* emb, const float* pos, float* x, int B, int L, int H,
+                         int n_rows, hipStream_t s);
+// x[b, l, :] += spk[speaker[b or 0], :]
+const char* launch_add_speaker(float* x, const float* spk, const int64_t* speaker, int n_spk_ids, int n_speakers,
+                               int B, int L, int H, hipStream_t s);
+// y = x + alpha[0] * table[pos(b, l)], pos = running count of x[b, l, 0] != 0 (0 where it is 0)
+// (posbuf: [B, L] int32 scratch)
+const char* launch_var_positions(const float* x, int32_t* posbuf, const float* table, int table_rows, const float* alpha,
+                                 float* y, int B, int L, int H, hipStream_t s);
+// out[row, o] = dot(x[row, :], w[o, :]) + b[o], o < O <= 2; rows >= lens[b] -> 0 when lens != null
+const char* launch_rowdot(const float* x, const float* w, const float* b, float* out, const int32_t* lens, int B, int L,
+                          int C, int O, hipStream_t s);
+// duration_rounded, integer durations, inclusive scan -> mel_lens; one block per utterance
+const char* launch_duration(const float* log_d, float d_control, float* dur, int32_t* cum, int64_t* mel_lens64,
+                            int32_t* mel_lens32, int B, int L, hipStream_t s);
+// pitch / energy bucket indices + x += pitch_emb[pidx] + energy_emb[eidx]
+const char* launch_variance_embed(float* x, float* pitch_pred /*[B,L,2], scaled in place by p_control*/,
+                                  const float* energy_pred, float p_control, float e_control, float f0_mean,
+                                  float f0_std, const float* energy_bins, int n_bins, const float* pitch_emb,
+                                  const float* energy_emb, int32_t* pitch_idx, int32_t* energy_idx, int B, int L, int H,
+                                  hipStream_t s);
+// length regulator fused with the decoder position add: y[b, t, :] = (t < mel_len[b] ? x[b, ph(t), :] : 0) + pos[t, :]
+const char* launch_length_regulate(const float* x, const int32_t* cum, const int32_t* mel_lens, const float* pos,
+                                   float* y, int B, int L, int T, int H, hipStream_t s);
+// [B, C, T] -> [B, T, C]
+const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s);
+// wav = tanh(conv7(lrelu_0.01(x))) with Cout = 1; pcm = (int16)(int32)(wav * 32768)
+const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,
+                             long long N, int C, int KW, hipStream_t s);
+
+}  // namespace e2etts

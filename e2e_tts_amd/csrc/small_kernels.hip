@@ -1,0 +1,435 @@
+// The memory-bound / integer kernels around the two MFMA kernels: embedding, LayerNorm, the variance
+// adaptor's integer decisions (duration rounding, f0 / energy buckets), the length regulator, the
+// vocoder's 1-channel output convolution.  fp32 throughout; float4 (16 B / lane) global accesses.
+#include <math.h>
+
+#include "kernels.h"
+
+namespace e2etts {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------- LayerNorm (one wavefront per row)
+template <int NV>  // float4 per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const int32_t* __restrict__ lens, int rows, int N, int C, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = C / 4;
+  float4* yr = reinterpret_cast<float4*>(y + (long long)row * C);
+  if (lens) {
+    const int b = row / N, t = row - b * N;
+    if (t >= lens[b]) {  // masked_fill(mask, 0) after the norm (reference U/blocks/transformer.py:182-187)
+      for (int i = lane; i < nv; i += 64) yr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+  }
+  const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * C);
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + i * 64;
+    v[i] = idx < nv ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float a = v[i].x - mean, b2 = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b2 * b2) + (c * c + d * d);
+    }
+  }
+  const float var = wave_sum(q) / (float)C;  // biased, as torch.nn.LayerNorm
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float4 g = g4[idx], bb = b4[idx];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + bb.x;
+      o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+      o.z = (v[i].z - mean) * rstd * g.z + bb.z;
+      o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+      yr[idx] = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- embedding + position table
+__global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb, const float* __restrict__ pos,
+                             float* __restrict__ x, int L, int H, int n_rows) {
+  const int row = blockIdx.x;  // b * L + l
+  const int l = row % L;
+  long long id = ids[row];
+  id = id < 0 ? 0 : (id >= n_rows ? n_rows - 1 : id);  // host validates; clamp keeps the access in bounds
+  const float4* e = reinterpret_cast<const float4*>(emb + id * H);
+  const float4* p = reinterpret_cast<const float4*>(pos + (long long)l * H);
+  float4* o = reinterpret_cast<float4*>(x + (long long)row * H);
+  for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
+    const float4 a = e[i], b = p[i];
+    o[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+__global__ void add_speaker_kernel(float* __restrict__ x, const float* __restrict__ spk, const int64_t* __restrict__ speaker,
+                                   int n_spk_ids, int n_speakers, int L, int H) {
+  const int row = blockIdx.x;
+  const int b = row / L;
+  long long sid = speaker[n_spk_ids == 1 ? 0 : b];
+  sid = sid < 0 ? 0 : (sid >= n_speakers ? n_speakers - 1 : sid);
+  const float4* e = reinterpret_cast<const float4*>(spk + sid * H);
+  float4* o = reinterpret_cast<float4*>(x + (long long)row * H);
+  for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
+    const float4 a = o[i], c = e[i];
+    o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+  }
+}
+
+// ---------------------------------------------------------------- variance-predictor positions
+// positions = cumsum(x[..., 0] != 0) * (x[..., 0] != 0)  (reference U/function.py:28-38 via U/sublayers.py:64),
+// y = x + alpha * table[positions] (U/layers.py:497-498).  One wavefront per utterance: shuffle scan + carry.
+__global__ __launch_bounds__(64) void var_positions_kernel(const float* __restrict__ x, int32_t* __restrict__ posbuf, int L, int H) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int carry = 0;
+  for (int l0 = 0; l0 < L; l0 += 64) {
+    const int l = l0 + lane;
+    const int nz = (l < L && x[((long long)b * L + l) * H] != 0.f) ? 1 : 0;
+    int v = nz;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(v, o);
+      if (lane >= o) v += u;
+    }
+    if (l < L) posbuf[b * L + l] = nz ? carry + v : 0;
+    carry += __shfl(v, 63);
+  }
+}
+
+__global__ void var_pos_add_kernel(const float* __restrict__ x, const int32_t* __restrict__ posbuf, const float* __restrict__ table,
+                                   int table_rows, const float* __restrict__ alpha, float* __restrict__ y, int H) {
+  const int row = blockIdx.x;
+  int pos = posbuf[row];
+  pos = pos >= table_rows ? table_rows - 1 : pos;  // host guarantees L + 1 <= table_rows
+  const float a = alpha[0];
+  const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * H);
+  const float4* tr = reinterpret_cast<const float4*>(table + (long long)pos * H);
+  float4* yr = reinterpret_cast<float4*>(y + (long long)row * H);
+  for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
+    const float4 v = xr[i], t = tr[i];
+    // x + (alpha * table): two roundings, as the reference computes it
+    yr[i] = make_float4(v.x + __fmul_rn(a, t.x), v.y + __fmul_rn(a, t.y), v.z + __fmul_rn(a, t.z), v.w + __fmul_rn(a, t.w));
+  }
+}
+
+// ---------------------------------------------------------------- small-odim Linear (one wavefront per row)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     const int32_t* __restrict__ lens, int rows, int L, int C, int O) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * C);
+  bool masked = false;
+  if (lens) {
+    const int b = row / L;
+    masked = (row - b * L) >= lens[b];
+  }
+  for (int o = 0; o < O; ++o) {
+    const float4* wr = reinterpret_cast<const float4*>(w + (long long)o * C);
+    float s = 0.f;
+    for (int i = lane; i < C / 4; i += 64) {
+      const float4 a = xr[i], c = wr[i];
+      s += (a.x * c.x + a.y * c.y) + (a.z * c.z + a.w * c.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[(long long)row * O + o] = masked ? 0.f : s + bias[o];
+  }
+}
+
+// ---------------------------------------------------------------- duration rounding + inclusive scan
+// duration_rounded = clamp(round(exp(log_d) - 1) * d_control, min = 0)   (reference U/layers.py:218-221;
+// torch.round = half-to-even = rintf).  Repeat count = max(int(d), 0) (U/layers.py:448-449).
+// One wavefront per utterance: __shfl_up inclusive scan over 64 phonemes at a time with a running carry.
+__global__ __launch_bounds__(64) void duration_kernel(const float* __restrict__ log_d, float d_control, float* __restrict__ dur,
+                                                      int32_t* __restrict__ cum, int64_t* __restrict__ mel64,
+                                                      int32_t* __restrict__ mel32, int L) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int carry = 0;
+  for (int l0 = 0; l0 < L; l0 += 64) {
+    const int l = l0 + lane;
+    float d = 0.f;
+    if (l < L) {
+      const float e = __fsub_rn(expf(log_d[b * L + l]), 1.0f);
+      d = fmaxf(__fmul_rn(rintf(e), d_control), 0.f);
+      dur[b * L + l] = d;
+    }
+    int v = (int)d;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(v, o);
+      if (lane >= o) v += u;
+    }
+    if (l < L) cum[b * L + l] = carry + v;
+    carry += __shfl(v, 63);
+  }
+  if (lane == 0) {
+    mel64[b] = carry;
+    mel32[b] = carry;
+  }
+}
+
+// ---------------------------------------------------------------- pitch / energy buckets + embedding add
+// f0 bucket: reference U/layers.py:145-154 + U/function.py:178-187 (constants :9-13); energy: torch.bucketize
+// (right = False) on linspace bins (U/layers.py:169).  Every fp32 operation is kept a separate rounding
+// (__f*_rn: no FMA contraction) so that the integer results track the reference's elementwise torch ops.
+__global__ __launch_bounds__(128) void variance_embed_kernel(float* __restrict__ x, float* __restrict__ pitch_pred,
+                                                             const float* __restrict__ energy_pred, float p_control,
+                                                             float e_control, float f0_mean, float f0_std,
+                                                             const float* __restrict__ energy_bins, int n_bins,
+                                                             const float* __restrict__ pitch_emb, const float* __restrict__ energy_emb,
+                                                             int32_t* __restrict__ pitch_idx, int32_t* __restrict__ energy_idx, int H,
+                                                             float mel_min, float mel_range) {
+  const int row = blockIdx.x;
+  const float f0 = __fmul_rn(pitch_pred[2 * row], p_control);
+  const float uvl = __fmul_rn(pitch_pred[2 * row + 1], p_control);
+  float f0d = __fadd_rn(__fmul_rn(f0, f0_std), f0_mean);
+  if (uvl > 0.f) f0d = 0.f;
+  float mel = __fmul_rn(1127.0f, logf(__fadd_rn(1.0f, __fdiv_rn(f0d, 700.0f))));
+  if (mel > 0.f) mel = __fadd_rn(__fdiv_rn(__fmul_rn(__fsub_rn(mel, mel_min), 254.0f), mel_range), 1.0f);
+  if (mel <= 1.f) mel = 1.f;
+  if (mel > 255.f) mel = 255.f;
+  int pidx = (int)__fadd_rn(mel, 0.5f);
+  pidx = pidx < 0 ? 0 : (pidx > n_bins - 1 ? n_bins - 1 : pidx);  // NaN guard only; the clamps above bound it
+  const float e = __fmul_rn(energy_pred[row], e_control);
+  int lo = 0, hi = n_bins - 1;  // first index with bins[idx] >= e; n_bins - 1 boundaries
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (energy_bins[mid] < e) lo = mid + 1; else hi = mid;
+  }
+  const int eidx = lo;
+  if (threadIdx.x == 0) {
+    pitch_pred[2 * row] = f0;
+    pitch_pred[2 * row + 1] = uvl;
+    pitch_idx[row] = pidx;
+    energy_idx[row] = eidx;
+  }
+  float4* xr = reinterpret_cast<float4*>(x + (long long)row * H);
+  const float4* pe = reinterpret_cast<const float4*>(pitch_emb + (long long)pidx * H);
+  const float4* ee = reinterpret_cast<const float4*>(energy_emb + (long long)eidx * H);
+  for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
+    const float4 a = xr[i], p = pe[i], q = ee[i];
+    xr[i] = make_float4((a.x + p.x) + q.x, (a.y + p.y) + q.y, (a.z + p.z) + q.z, (a.w + p.w) + q.w);
+  }
+}
+
+// ---------------------------------------------------------------- length regulator (+ decoder position add)
+// Reference U/layers.py:429-451: repeat phoneme row i duration[i] times, concatenate, zero-pad to the batch
+// maximum; here frame t finds its phoneme by binary search in the inclusive duration scan.
+__global__ __launch_bounds__(128) void length_regulate_kernel(const float* __restrict__ x, const int32_t* __restrict__ cum,
+                                                              const int32_t* __restrict__ mel_lens, const float* __restrict__ pos,
+                                                              float* __restrict__ y, int L, int T, int H) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  const float4* pr = reinterpret_cast<const float4*>(pos + (long long)t * H);
+  float4* yr = reinterpret_cast<float4*>(y + ((long long)b * T + t) * H);
+  if (t >= mel_lens[b]) {
+    for (int i = threadIdx.x; i < H / 4; i += blockDim.x) yr[i] = pr[i];
+    return;
+  }
+  const int32_t* c = cum + b * L;
+  int lo = 0, hi = L - 1;  // smallest i with cum[i] > t
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (c[mid] > t) hi = mid; else lo = mid + 1;
+  }
+  const float4* xr = reinterpret_cast<const float4*>(x + ((long long)b * L + lo) * H);
+  for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
+    const float4 a = xr[i], p = pr[i];
+    yr[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+
+// ---------------------------------------------------------------- [B, C, T] -> [B, T, C]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    tile[i][tx] = (c < C && t < T) ? in[((long long)b * C + c) * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    if (t < T && c < C) out[((long long)b * T + t) * C + c] = tile[tx][i];
+  }
+}
+
+// ---------------------------------------------------------------- conv_post: lrelu(0.01) -> Conv1d(C -> 1, k7) -> tanh
+// Reference V/generator.py:49-51 (F.leaky_relu default slope 0.01).  Also emits the int16 PCM exactly as
+// TTS.combine_audio does (API/utils.py:112,117): fp32 wav * 32768.0, then numpy's float -> int16 cast,
+// i.e. truncation toward zero through a 32-bit integer (so exactly +1.0 wraps to -32768, as numpy does on x86).
+template <int TPB>
+__global__ __launch_bounds__(TPB) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ wav,
+                                                        int16_t* __restrict__ pcm, long long N, int C, int KW) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ldx = C + 4;
+  const int pad = (KW - 1) / 2;
+  const int rows = TPB + KW - 1;
+  float* xs = sm;
+  float* ws = sm + rows * ldx;
+  const int b = blockIdx.y;
+  const long long t0 = (long long)blockIdx.x * TPB;
+  const float* xb = x + (long long)b * N * C;
+  const int c4n = C / 4;
+  for (int i = threadIdx.x; i < rows * c4n; i += TPB) {
+    const int r = i / c4n, c = (i - r * c4n) * 4;
+    const long long t = t0 - pad + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < N) {
+      v = *reinterpret_cast<const float4*>(xb + t * C + c);
+      v.x = v.x >= 0.f ? v.x : v.x * 0.01f;
+      v.y = v.y >= 0.f ? v.y : v.y * 0.01f;
+      v.z = v.z >= 0.f ? v.z : v.z * 0.01f;
+      v.w = v.w >= 0.f ? v.w : v.w * 0.01f;
+    }
+    *reinterpret_cast<float4*>(xs + r * ldx + c) = v;
+  }
+  for (int i = threadIdx.x; i < KW * C; i += TPB) ws[i] = w[i];
+  __syncthreads();
+  const long long t = t0 + threadIdx.x;
+  if (t >= N) return;
+  float acc = 0.f;
+  for (int j = 0; j < KW; ++j) {
+    const float* xr = xs + (threadIdx.x + j) * ldx;
+    const float* wr = ws + j * C;
+    for (int c = 0; c < C; c += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(xr + c);
+      const float4 ww = *reinterpret_cast<const float4*>(wr + c);
+      acc += (a.x * ww.x + a.y * ww.y) + (a.z * ww.z + a.w * ww.w);
+    }
+  }
+  const float v = tanhf(acc + bias[0]);
+  if (wav) wav[(long long)b * N + t] = v;
+  if (pcm) pcm[(long long)b * N + t] = (int16_t)(int32_t)__fmul_rn(v, 32768.0f);
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH(name) (hipGetLastError() == hipSuccess ? nullptr : name ": launch failed")
+
+const char* launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, const int32_t* lens,
+                             int B, int N, int C, float eps, hipStream_t s) {
+  if (!x || !y || !gamma || !beta) return "layernorm: null pointer";
+  if (C % 4 || C <= 0 || C > 1024) return "layernorm: C must be a multiple of 4 in (0, 1024]";
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return "layernorm: unaligned pointer";
+  const int rows = B * N;
+  if (rows <= 0) return "layernorm: bad dims";
+  dim3 grid((rows + 3) / 4);
+  const int nv = (C / 4 + 63) / 64;
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, rows, N, C, eps); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, rows, N, C, eps); break;
+    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, rows, N, C, eps); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, y, gamma, beta, lens, rows, N, C, eps); break;
+  }
+  return CHECK_LAUNCH("layernorm");
+}
+
+const char* launch_embed(const int64_t* ids, const float* emb, const float* pos, float* x, int B, int L, int H,
+                         int n_rows, hipStream_t s) {
+  if (!ids || !emb || !pos || !x) return "embed: null pointer";
+  if (H % 4 || B <= 0 || L <= 0) return "embed: bad dims";
+  hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(128), 0, s, ids, emb, pos, x, L, H, n_rows);
+  return CHECK_LAUNCH("embed");
+}
+
+const char* launch_add_speaker(float* x, const float* spk, const int64_t* speaker, int n_spk_ids, int n_speakers,
+                               int B, int L, int H, hipStream_t s) {
+  if (!x || !spk || !speaker) return "add_speaker: null pointer";
+  if (n_spk_ids != 1 && n_spk_ids != B) return "add_speaker: speaker must have 1 or B entries";
+  hipLaunchKernelGGL(add_speaker_kernel, dim3(B * L), dim3(128), 0, s, x, spk, speaker, n_spk_ids, n_speakers, L, H);
+  return CHECK_LAUNCH("add_speaker");
+}
+
+const char* launch_rowdot(const float* x, const float* w, const float* b, float* out, const int32_t* lens, int B, int L,
+                          int C, int O, hipStream_t s) {
+  if (!x || !w || !b || !out) return "rowdot: null pointer";
+  if (C % 4 || O <= 0 || O > 4) return "rowdot: bad dims";
+  const int rows = B * L;
+  hipLaunchKernelGGL(rowdot_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, out, lens, rows, L, C, O);
+  return CHECK_LAUNCH("rowdot");
+}
+
+const char* launch_duration(const float* log_d, float d_control, float* dur, int32_t* cum, int64_t* mel_lens64,
+                            int32_t* mel_lens32, int B, int L, hipStream_t s) {
+  if (!log_d || !dur || !cum || !mel_lens64 || !mel_lens32) return "duration: null pointer";
+  hipLaunchKernelGGL(duration_kernel, dim3(B), dim3(64), 0, s, log_d, d_control, dur, cum, mel_lens64, mel_lens32, L);
+  return CHECK_LAUNCH("duration");
+}
+
+const char* launch_variance_embed(float* x, float* pitch_pred, const float* energy_pred, float p_control, float e_control,
+                                  float f0_mean, float f0_std, const float* energy_bins, int n_bins, const float* pitch_emb,
+                                  const float* energy_emb, int32_t* pitch_idx, int32_t* energy_idx, int B, int L, int H,
+                                  hipStream_t s) {
+  if (!x || !pitch_pred || !energy_pred || !energy_bins || !pitch_emb || !energy_emb || !pitch_idx || !energy_idx)
+    return "variance_embed: null pointer";
+  if (n_bins != 256) return "variance_embed: the f0 coarse coding is defined for 256 bins (reference U/function.py:9)";
+  // f0_mel_min / max: numpy float64 constants, used by torch as fp32 scalars (U/function.py:12-13,180)
+  const double mel_min = 1127.0 * log(1.0 + 50.0 / 700.0), mel_max = 1127.0 * log(1.0 + 1100.0 / 700.0);
+  hipLaunchKernelGGL(variance_embed_kernel, dim3(B * L), dim3(128), 0, s, x, pitch_pred, energy_pred, p_control, e_control,
+                     f0_mean, f0_std, energy_bins, n_bins, pitch_emb, energy_emb, pitch_idx, energy_idx, H, (float)mel_min,
+                     (float)(mel_max - mel_min));
+  return CHECK_LAUNCH("variance_embed");
+}
+
+const char* launch_length_regulate(const float* x, const int32_t* cum, const int32_t* mel_lens, const float* pos, float* y,
+                                   int B, int L, int T, int H, hipStream_t s) {
+  if (!x || !cum || !mel_lens || !pos || !y) return "length_regulate: null pointer";
+  if (T <= 0 || H % 4) return "length_regulate: bad dims";
+  hipLaunchKernelGGL(length_regulate_kernel, dim3(T, B), dim3(128), 0, s, x, cum, mel_lens, pos, y, L, T, H);
+  return CHECK_LAUNCH("length_regulate");
+}
+
+const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s) {
+  if (!in || !out) return "transpose: null pointer";
+  hipLaunchKernelGGL(transpose_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, in, out, C, T);
+  return CHECK_LAUNCH("transpose");
+}
+
+const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,
+                             long long N, int C, int KW, hipStream_t s) {
+  if (!x || !w || !bias) return "conv_post: null pointer";
+  if (C % 4 || C <= 0 || C > 128 || KW <= 0 || KW > 15 || !(KW & 1)) return "conv_post: bad dims";
+  constexpr int TPB = 256;
+  const size_t lds = ((size_t)(TPB + KW - 1) * (C + 4) + (size_t)KW * C) * sizeof(float);
+  if (lds > 64 * 1024) return "conv_post: LDS tile exceeds 64 KiB";
+  dim3 grid((unsigned)((N + TPB - 1) / TPB), B);
+  hipLaunchKernelGGL(conv_post_kernel<TPB>, grid, dim3(TPB), lds, s, x, w, bias, wav, pcm, N, C, KW);
+  return CHECK_LAUNCH("conv_post");
+}
+
+const char* launch_var_positions(const float* x, int32_t* posbuf, const float* table, int table_rows, const float* alpha,
+                                  float* y, int B, int L, int H, hipStream_t s) {
+  if (!x || !posbuf || !table || !alpha || !y) return "var_positions: null pointer";
+  if (L + 1 > table_rows) return "var_positions: sequence longer than the shipped position table";
+  hipLaunchKernelGGL(var_positions_kernel, dim3(B), dim3(64), 0, s, x, posbuf, L, H);
+  hipLaunchKernelGGL(var_pos_add_kernel, dim3(B * L), dim3(128), 0, s, x, posbuf, table, table_rows, alpha, y, H);
+  return CHECK_LAUNCH("var_positions");
+}
+
+}  // namespace e2etts

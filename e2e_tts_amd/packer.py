@@ -1,0 +1,213 @@
+"""state_dict -> packed weight blob for the HIP engine.
+
+This is the "PyTorch-ROCm only for weight load / layout" part of the design:
+it reads the two reference checkpoints' state dicts (the formats written by
+reference e2e_tts/src/tools/tools_for_model.py:155-177 and loaded at
+API/utils.py:48-49,54-55) and lays the tensors out the way the kernels read
+them:
+
+* Conv1d weights [Cout, Cin, K] -> [Cout, K, Cin] (tap-major rows: one GEMM K axis);
+* w_qs / w_ks / w_vs stacked into one [3H, H] projection;
+* weight_norm folded, w = g * v / ||v|| (reference V/generator.py:18,23,33; fp32 via
+  torch._weight_norm, the same routine the reference's parametrisation calls);
+* eval-mode BatchNorm1d folded into the Postnet convolutions (U/layers.py:530-553):
+  w' = w * gamma / sqrt(var + 1e-5), b' = (b - mean) * gamma / sqrt(var + 1e-5) + beta;
+* ConvTranspose1d(k = 2s, stride s, pad s/2) rewritten as a 3-tap convolution with s * Cout output
+  channels (polyphase form; zero where a tap does not reach a phase);
+* both sinusoid tables precomputed on the host (U/blocks/utils.py:14-34 in float64 numpy;
+  U/sublayers.py:28-44 with the reference's own torch fp32 operations).
+
+Blob layout (little endian): 32-byte header {magic "E2ETTSW1", u32 version = 1, u32 n_entries,
+u64 data_offset, u64 total_bytes}, n_entries x {char name[64], u64 offset, u64 numel}, then fp32
+tensors at 256-byte aligned offsets.
+"""
+from __future__ import annotations
+
+import math
+import struct
+from collections import OrderedDict
+from typing import Dict, Mapping
+
+import numpy as np
+
+from .config import EngineDims
+from .synth_weights import sinusoid_table
+
+MAGIC = b"E2ETTSW1"
+ALIGN = 256
+VAR_POS_INIT_ROWS = 4096  # SinusoidalPositionalEmbedding(idim, 0, init_size=4096), reference U/layers.py:488
+
+
+def _np(t) -> np.ndarray:
+    if isinstance(t, np.ndarray):
+        return t
+    return t.detach().cpu().numpy()
+
+
+def fold_weight_norm(g, v) -> np.ndarray:
+    """w = g * v / ||v||, norm over all dims but 0 (weight_norm default dim=0)."""
+    try:
+        import torch
+        return torch._weight_norm(torch.as_tensor(_np(v)), torch.as_tensor(_np(g)), 0).numpy()
+    except ImportError:  # pragma: no cover - torch is part of the image
+        v64 = _np(v).astype(np.float64)
+        norm = np.sqrt((v64 * v64).sum(axis=tuple(range(1, v64.ndim)), keepdims=True))
+        return (_np(g).astype(np.float64) * v64 / norm).astype(np.float32)
+
+
+def variance_position_table(rows: int, dim: int) -> np.ndarray:
+    """The fairseq-style table of reference U/sublayers.py:28-44, built with the same torch fp32 ops
+    (the fp32 angle pos * exp(-k * c) is sensitive to the last bit of exp, so torch is used, not numpy)."""
+    import torch
+    half = dim // 2
+    emb = math.log(10000) / (half - 1)
+    emb = torch.exp(torch.arange(half, dtype=torch.float) * -emb)
+    emb = torch.arange(rows, dtype=torch.float).unsqueeze(1) * emb.unsqueeze(0)
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1).view(rows, -1)
+    if dim % 2 == 1:
+        emb = torch.cat([emb, torch.zeros(rows, 1)], dim=1)
+    emb[0, :] = 0  # padding_idx = 0
+    return emb.numpy()
+
+
+def conv_rows(w: np.ndarray) -> np.ndarray:
+    """[Cout, Cin, K] -> [Cout, K * Cin] tap-major."""
+    return np.ascontiguousarray(w.transpose(0, 2, 1)).reshape(w.shape[0], -1)
+
+
+def polyphase_upsampler(w: np.ndarray, b: np.ndarray, stride: int):
+    """ConvTranspose1d weight [Cin, Cout, K = 2s] (pad s/2) -> 3-tap conv weight [s*Cout, 3*Cin], bias [s*Cout].
+
+    out[s*q + r] = sum_i x[i] . w[:, :, s*q + r + pad - s*i]; with taps m = 0, 1, 2 <-> i = q - 1 + m the
+    kernel index is kk = r + pad + s * (1 - m), used when 0 <= kk < K.
+    """
+    cin, cout, K = w.shape
+    s = stride
+    pad = (K - s) // 2
+    assert K == 2 * s and s % 2 == 0
+    out = np.zeros((s, cout, 3, cin), dtype=np.float32)
+    for r in range(s):
+        for m in range(3):
+            kk = r + pad + s * (1 - m)
+            if 0 <= kk < K:
+                out[r, :, m, :] = w[:, :, kk].T
+    return out.reshape(s * cout, 3 * cin), np.tile(b, s).astype(np.float32)
+
+
+def pack_tensors(dims: EngineDims, acoustic: Mapping[str, object], vocoder: Mapping[str, object]) -> "OrderedDict[str, np.ndarray]":
+    """Engine tensor name -> fp32 array (see bind_all() in csrc/engine.hip for the consumer)."""
+    A = {k: _np(v) for k, v in acoustic.items()}
+    V = {k: _np(v) for k, v in vocoder.items()}
+    H = dims.hidden
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def need(sd, key, shape=None):
+        if key not in sd:
+            raise KeyError(f"checkpoint has no tensor {key!r}")
+        t = sd[key]
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{key}: shape {tuple(t.shape)} != expected {tuple(shape)}")
+        return t.astype(np.float32) if t.dtype.kind == "f" else t
+
+    out["enc.emb"] = need(A, "encoder.src_word_emb.weight", (dims.n_symbols + 1, H))
+    out["enc.pos"] = need(A, "encoder.position_enc", (1, dims.max_seq_len + 1, H))[0]
+    out["dec.pos"] = need(A, "decoder.position_enc", (1, dims.max_seq_len + 1, H))[0]
+    out["pos.regen"] = sinusoid_table(dims.pos_table_rows, H)
+    out["spk.emb"] = need(A, "speaker_emb.weight", (dims.n_speakers, H))
+    for side, short, n in (("encoder", "enc", dims.enc_layers), ("decoder", "dec", dims.dec_layers)):
+        for l in range(n):
+            p = f"{side}.layer_stack.{l}"
+            q = f"{short}.{l}."
+            out[q + "wqkv"] = np.concatenate([need(A, f"{p}.slf_attn.{w}.weight", (H, H)) for w in ("w_qs", "w_ks", "w_vs")], 0)
+            out[q + "bqkv"] = np.concatenate([need(A, f"{p}.slf_attn.{w}.bias", (H,)) for w in ("w_qs", "w_ks", "w_vs")], 0)
+            out[q + "wo"] = need(A, f"{p}.slf_attn.fc.weight", (H, H))
+            out[q + "bo"] = need(A, f"{p}.slf_attn.fc.bias", (H,))
+            out[q + "ln1.g"] = need(A, f"{p}.slf_attn.layer_norm.weight", (H,))
+            out[q + "ln1.b"] = need(A, f"{p}.slf_attn.layer_norm.bias", (H,))
+            out[q + "w1"] = conv_rows(need(A, f"{p}.pos_ffn.w_1.weight", (dims.ffn_dim, H, dims.ffn_k1)))
+            out[q + "b1"] = need(A, f"{p}.pos_ffn.w_1.bias", (dims.ffn_dim,))
+            out[q + "w2"] = conv_rows(need(A, f"{p}.pos_ffn.w_2.weight", (H, dims.ffn_dim, dims.ffn_k2)))
+            out[q + "b2"] = need(A, f"{p}.pos_ffn.w_2.bias", (H,))
+            out[q + "ln2.g"] = need(A, f"{p}.pos_ffn.layer_norm.weight", (H,))
+            out[q + "ln2.b"] = need(A, f"{p}.pos_ffn.layer_norm.bias", (H,))
+    va = "variance_adaptor"
+    for name, short, layers, kern, chans, odim in (
+            ("duration_predictor", "dur", dims.dur_layers, dims.dur_kernel, dims.dur_chans, 1),
+            ("pitch_predictor", "pitch", dims.var_layers, dims.var_kernel, dims.var_chans, 2),
+            ("energy_predictor", "energy", dims.var_layers, dims.var_kernel, dims.var_chans, 1)):
+        for i in range(layers):
+            cin = H if i == 0 else chans
+            p = f"{va}.{name}.conv.{i}"
+            out[f"{short}.{i}.w"] = conv_rows(need(A, f"{p}.1.weight", (chans, cin, kern)))
+            out[f"{short}.{i}.b"] = need(A, f"{p}.1.bias", (chans,))
+            out[f"{short}.{i}.g"] = need(A, f"{p}.3.weight", (chans,))
+            out[f"{short}.{i}.beta"] = need(A, f"{p}.3.bias", (chans,))
+        out[f"{short}.lin.w"] = need(A, f"{va}.{name}.linear.weight", (odim, chans))
+        out[f"{short}.lin.b"] = need(A, f"{va}.{name}.linear.bias", (odim,))
+        if short != "dur":
+            out[f"{short}.alpha"] = need(A, f"{va}.{name}.pos_embed_alpha", (1,))
+    out["var.pos"] = variance_position_table(VAR_POS_INIT_ROWS, H)
+    out["pitch.emb"] = need(A, f"{va}.pitch_embedding.weight", (dims.n_bins, H))
+    out["energy.emb"] = need(A, f"{va}.energy_embedding.weight", (dims.n_bins, H))
+    out["energy.bins"] = need(A, f"{va}.energy_bins", (dims.n_bins - 1,))
+    out["mel.w"] = need(A, "mel_linear.weight", (dims.n_mel, H))
+    out["mel.b"] = need(A, "mel_linear.bias", (dims.n_mel,))
+    for i in range(dims.postnet_layers):
+        p = f"postnet.convolutions.{i}"
+        w = need(A, f"{p}.0.conv.weight").astype(np.float64)
+        b = need(A, f"{p}.0.conv.bias").astype(np.float64)
+        scale = need(A, f"{p}.1.weight").astype(np.float64) / np.sqrt(need(A, f"{p}.1.running_var").astype(np.float64) + 1e-5)
+        wf = (w * scale[:, None, None]).astype(np.float32)
+        bf = ((b - need(A, f"{p}.1.running_mean").astype(np.float64)) * scale + need(A, f"{p}.1.bias").astype(np.float64)).astype(np.float32)
+        out[f"post.{i}.w"] = conv_rows(wf)
+        out[f"post.{i}.b"] = bf
+
+    def voc_weight(prefix):
+        if prefix + ".weight_v" in V:
+            return fold_weight_norm(need(V, prefix + ".weight_g"), need(V, prefix + ".weight_v")), need(V, prefix + ".bias")
+        return need(V, prefix + ".weight"), need(V, prefix + ".bias")  # remove_weight_norm()'d checkpoint
+
+    w, b = voc_weight("conv_pre")
+    out["voc.pre.w"], out["voc.pre.b"] = conv_rows(w), b
+    nk = len(dims.voc_rb_kernel)
+    for i, s in enumerate(dims.voc_up_rate):
+        w, b = voc_weight(f"ups.{i}")
+        out[f"voc.up.{i}.w"], out[f"voc.up.{i}.b"] = polyphase_upsampler(w, b, s)
+        for j in range(nk):
+            idx = i * nk + j
+            for m in range(len(dims.voc_rb_dil[j])):
+                for cs, short in (("convs1", "c1"), ("convs2", "c2")):
+                    w, b = voc_weight(f"resblocks.{idx}.{cs}.{m}")
+                    out[f"voc.rb.{idx}.{short}.{m}.w"], out[f"voc.rb.{idx}.{short}.{m}.b"] = conv_rows(w), b
+    w, b = voc_weight("conv_post")
+    out["voc.post.w"], out["voc.post.b"] = conv_rows(w), b
+    return OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32)) for k, v in out.items())
+
+
+def build_blob(tensors: Mapping[str, np.ndarray]) -> np.ndarray:
+    """Serialise to the flat image e2etts_load_weights() takes.  Returns a uint8 array."""
+    n = len(tensors)
+    header_size = 32
+    dir_size = n * 80
+    data_offset = (header_size + dir_size + ALIGN - 1) // ALIGN * ALIGN
+    entries = []
+    off = data_offset
+    for name, t in tensors.items():
+        raw = name.encode()
+        if len(raw) > 63:
+            raise ValueError(f"tensor name too long: {name}")
+        entries.append((raw, off, t.size))
+        off = (off + t.size * 4 + ALIGN - 1) // ALIGN * ALIGN
+    total = off
+    blob = np.zeros(total, dtype=np.uint8)
+    blob[:header_size] = np.frombuffer(struct.pack("<8sIIQQ", MAGIC, 1, n, data_offset, total), dtype=np.uint8)
+    pos = header_size
+    for (raw, o, numel), t in zip(entries, tensors.values()):
+        blob[pos:pos + 80] = np.frombuffer(struct.pack("<64sQQ", raw, o, numel), dtype=np.uint8)
+        pos += 80
+        blob[o:o + numel * 4] = t.reshape(-1).view(np.uint8)
+    return blob
+
+
+def pack(dims: EngineDims, acoustic: Mapping[str, object], vocoder: Mapping[str, object]) -> np.ndarray:
+    return build_blob(pack_tensors(dims, acoustic, vocoder))

@@ -1,0 +1,146 @@
+/*
+ * e2etts.h -- C ABI of the MI355X-native FastSpeech2 + HiFi-GAN inference engine.
+ *
+ * The reference (InterlinkLabs/e2e-tts) has no FFI / plugin interface: its hot path is a stack of
+ * Python classes calling torch.  This header is the boundary this project puts
+ * underneath Python mirrors of those classes; every entry point names the reference call it serves.
+ * Paths are relative to the reference root; U/ = e2e_tts/models/acoustic/unsupervised_fastspeech2/,
+ * V/ = e2e_tts/models/vocoder/, API/ = e2e_tts/src/api/.
+ *
+ * Conventions
+ *  - plain C, no torch types; every function returns 0 on success or a negative E2ETTS_E* code, and
+ *    e2etts_last_error() gives the message (no exceptions cross the boundary);
+ *  - data pointers may be host OR device memory: copies use hipMemcpyDefault, so a caller that keeps
+ *    its buffers in HBM (bench.py, the torch-tensor mirrors) pays no PCIe transfer;
+ *  - one engine = one GPU + one HIP stream; calls on one engine are serialised by an internal mutex;
+ *    distinct engines are independent (one process per GPU in multi-GPU runs);
+ *  - all activations are fp32, channels-last ([B, N, C]); weights come packed by
+ *    e2e_tts_amd/packer.py (weight-norm and BatchNorm folded, conv weights tap-major).
+ */
+#ifndef E2ETTS_H
+#define E2ETTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E2ETTS_MAX_STAGES 8
+#define E2ETTS_MAX_RB_KERNELS 4
+#define E2ETTS_MAX_DILATIONS 4
+
+#define E2ETTS_OK 0
+#define E2ETTS_EINVAL (-1)   /* bad argument / shape (the Python mirror raises ValueError) */
+#define E2ETTS_EHIP (-2)     /* HIP runtime error */
+#define E2ETTS_ESTATE (-3)   /* call order (e.g. vocoder before weights are loaded) */
+#define E2ETTS_ENOMEM (-4)
+#define E2ETTS_EKEY (-5)     /* tensor missing from the weight blob (KeyError) */
+
+/* Dimensions parsed from the reference's config.yaml (API/utils.py:34; e2e_tts/config/model_config.yaml). */
+typedef struct e2etts_config {
+  int32_t n_symbols;      /* len(symbols) = 131; the embedding has n_symbols + 1 rows (U/blocks/transformer.py:25) */
+  int32_t n_speakers;
+  int32_t n_mel;          /* audio.mel.channels */
+  int32_t hidden;         /* encoder_hidden == decoder_hidden */
+  int32_t enc_layers, dec_layers;
+  int32_t n_head;
+  int32_t ffn_dim;        /* conv_filter_size */
+  int32_t ffn_k1, ffn_k2; /* conv_kernel_size */
+  int32_t max_seq_len;
+  int32_t dur_layers, dur_kernel, dur_chans;
+  int32_t var_layers, var_kernel, var_chans;
+  int32_t n_bins;
+  int32_t postnet_layers, postnet_dim, postnet_kernel;
+  int32_t voc_init_ch;
+  int32_t voc_stages;
+  int32_t voc_up_rate[E2ETTS_MAX_STAGES];
+  int32_t voc_up_kernel[E2ETTS_MAX_STAGES];
+  int32_t voc_n_kernels;
+  int32_t voc_rb_kernel[E2ETTS_MAX_RB_KERNELS];
+  int32_t voc_n_dil;
+  int32_t voc_rb_dil[E2ETTS_MAX_RB_KERNELS][E2ETTS_MAX_DILATIONS];
+  int32_t hop_length;
+  int32_t sample_rate;
+  int32_t pos_table_rows; /* rows of the regenerated sinusoid table shipped in the blob */
+  float f0_mean, f0_std;  /* stats.json "f0" (U/layers.py:152) */
+} e2etts_config;
+
+typedef struct e2etts_engine e2etts_engine;
+
+/* Library / build identification. */
+const char* e2etts_version(void);
+
+/* Last error message of this engine (or of a failed e2etts_create when engine == NULL). */
+const char* e2etts_last_error(const e2etts_engine* engine);
+
+/* Replaces: TTS.__init__ model construction + .to(device) (API/utils.py:41-56). */
+int e2etts_create(int device_id, const e2etts_config* cfg, e2etts_engine** out);
+void e2etts_destroy(e2etts_engine* engine);
+
+/* Replaces: load_state_dict for both models (API/utils.py:48-49,54-55).  `blob` is the packed weight
+ * image (host or device memory; a device image is what a RCCL broadcast from rank 0 leaves behind --
+ * SURVEY.md 8(e)); it is copied into engine-owned HBM. */
+int e2etts_load_weights(e2etts_engine* engine, const void* blob, size_t nbytes);
+
+/* Replaces: UnsupervisedFastSpeech2.inference (U/model.py:155-194).
+ *   ids  [B, L] int64, lens [B] int64 (1 <= lens[b] <= L), speaker [n_spk_ids] int64 with
+ *   n_spk_ids == 1 (broadcast, as API/utils.py:133 does) or == B.
+ * Outputs (each may be NULL): dur [B, L] fp32 (duration_rounded), mel_lens [B] int64, T_out = max mel
+ * length, pitch_idx / energy_idx [B, L] int32 (the bucket indices of U/function.py:178-187 and
+ * U/layers.py:169), log_dur [B, L], pitch_pred [B, L, 2], energy_pred [B, L].
+ * mel / mel_post stay resident; read them with e2etts_fetch_mel.  One host sync (for T). */
+int e2etts_acoustic(e2etts_engine* engine, const int64_t* ids, const int64_t* lens, int B, int L,
+                    const int64_t* speaker, int n_spk_ids, float d_control, float p_control, float e_control,
+                    float* dur_out, int64_t* mel_lens_out, int* T_out, int32_t* pitch_idx_out, int32_t* energy_idx_out,
+                    float* log_dur_out, float* pitch_pred_out, float* energy_pred_out);
+
+/* Copies of the resident results of the last e2etts_acoustic: mel, mel_post [B, T, n_mel] (either may be NULL). */
+int e2etts_fetch_mel(e2etts_engine* engine, float* mel, float* mel_post);
+
+/* Debug / parity taps of the last e2etts_acoustic: which = "enc_out" [B, L, H] | "dec_out" [B, T, H]. */
+int e2etts_fetch_tap(e2etts_engine* engine, const char* which, float* out, size_t n_floats);
+
+/* Replaces: HifiGan.forward (V/generator.py:37-53) on mel [B, n_mel, T] (the reference layout,
+ * channels-first, as API/utils.py:144 passes it) or, when mel == NULL, on the resident mel_post of the
+ * last e2etts_acoustic.  Outputs (each may be NULL): wav [B, T*hop] fp32 in (-1, 1);
+ * pcm [B, T*hop] int16 = trunc(wav * 32768) as TTS.combine_audio computes it (API/utils.py:111-117). */
+int e2etts_vocoder(e2etts_engine* engine, const float* mel_bct, int B, int T, float* wav_out, int16_t* pcm_out);
+
+/* Same, mel given channels-last [B, T, n_mel] (the engine's native layout; no transpose). */
+int e2etts_vocoder_btc(e2etts_engine* engine, const float* mel_btc, int B, int T, float* wav_out, int16_t* pcm_out);
+
+/* Replaces one iteration of the TTS.inference batch loop (API/utils.py:130-148): acoustic -> vocoder.
+ * pcm_out [B, T*hop] int16 (rows padded to the batch maximum; valid samples of row b = mel_lens[b]*hop),
+ * mel_lens_out [B]. T_out receives T.  pcm_capacity = number of int16 the caller's buffer holds; if it is
+ * too small E2ETTS_EINVAL is returned with T_out set, and the result can be fetched with e2etts_fetch_pcm. */
+int e2etts_synthesize(e2etts_engine* engine, const int64_t* ids, const int64_t* lens, int B, int L,
+                      const int64_t* speaker, int n_spk_ids, float d_control, float p_control, float e_control,
+                      int16_t* pcm_out, size_t pcm_capacity, int64_t* mel_lens_out, int* T_out);
+int e2etts_fetch_pcm(e2etts_engine* engine, int16_t* pcm_out, size_t capacity);
+int e2etts_fetch_wav(e2etts_engine* engine, float* wav_out, size_t capacity);
+
+/* Per-kernel-class timing with HIP events on the engine's stream (bench.py roofline leg).
+ * enable != 0 starts recording (and clears counters); e2etts_profile_read fills up to `cap` records. */
+typedef struct e2etts_kernel_stat {
+  char name[48];
+  uint64_t launches;
+  double ms;      /* sum of launch durations */
+  double flops;   /* algorithmic FLOPs (2 x MAC) of those launches */
+  double bytes;   /* algorithmic bytes (operands read once + result written once) */
+} e2etts_kernel_stat;
+int e2etts_profile_enable(e2etts_engine* engine, int enable);
+int e2etts_profile_read(e2etts_engine* engine, e2etts_kernel_stat* out, int cap);
+
+/* Bytes of HBM currently owned by the engine (weights + workspace). */
+size_t e2etts_device_bytes(const e2etts_engine* engine);
+
+/* The engine's stream as a hipStream_t cast to void* (so a caller can order its own work after ours). */
+void* e2etts_stream(e2etts_engine* engine);
+int e2etts_sync(e2etts_engine* engine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E2ETTS_H */

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio samples / second of the FastSpeech2 + HiFi-GAN hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one pass of the hot path (ids -> encoder -> variance adaptor -> length regulator -> decoder ->
+postnet -> vocoder -> int16 PCM) over one batch of synthetic text, i.e. one iteration of the reference's
+TTS.inference loop (reference e2e_tts/src/api/utils.py:130-148).  Workload (BASELINE.json metric):
+batch 32 per GPU, fixed-length synthetic text L = 128 phonemes, 6 frames / phoneme -> T = 768 frames =
+196 608 samples (8.92 s of 22.05 kHz audio) per utterance; default-config random-init weights; fp32.
+Inputs (ids, lens, speaker) are resident in HBM before the timed region and the PCM stays in HBM; the
+host-inclusive rate is printed to stderr and recorded in DESIGN.md.
+
+Multi-GPU: utterances shard across ranks with no data-path collective ("scaling": "weak", 32 utterances per
+GPU); RCCL is used once, to broadcast the packed weight blob from rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (vector = matrix, v_mfma_f32_32x32x2_f32)
+BATCH = 32
+PHONEMES = 128
+FRAMES_PER_PHONEME = 6
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg, stats, ac_state, voc_state):
+    """The numpy oracle (a port of the reference's CPU path) timed on this host's cores on a bounded sample
+    of the same workload: B = 1, L = 48 phonemes -> 288 frames = 73 728 samples (3.3 s of audio)."""
+    from oracle import ref_numpy as orc
+    L = 48
+    rng = np.random.Generator(np.random.PCG64(1))
+    ids = rng.integers(4, 131, size=(1, L)).astype(np.int64)
+    lens = np.array([L], np.int64)
+    ac = orc.AcousticOracle(ac_state, cfg, stats)
+    voc = orc.VocoderOracle(voc_state, cfg)
+    t0 = time.perf_counter()
+    (mel, mel_post, dur), mel_lens = ac.inference(np.array([1]), ids, lens)
+    wav = voc.forward(mel_post.transpose(0, 2, 1))
+    dt = time.perf_counter() - t0
+    samples = int(mel_lens.sum()) * cfg["audio"]["stft"]["hop_length"]
+    assert wav.shape[-1] == samples
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return {"value": samples / dt, "unit": "audio samples/s", "cores": cores, "kind": "port",
+            "sample": f"numpy oracle, B=1 L={L} -> T={int(mel_lens[0])} frames ({samples} samples), {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=BATCH)
+    args = ap.parse_args()
+
+    import torch
+    from e2e_tts_amd import config as cfgmod, packer, synth_weights as sw
+    from e2e_tts_amd._lib import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = cfgmod.default_config()
+    stats = cfgmod.DEFAULT_STATS
+    dims = cfgmod.dims_from_config(cfg, stats, n_speakers=4)
+    hop = dims.hop_length
+    ac_state = voc_state = None
+    # rank 0 packs the weights; the blob travels to the other GPUs as ONE RCCL broadcast over xGMI
+    if rank == 0:
+        ac_state = sw.make_acoustic_state(cfg, stats, 4, seed=1234, mode="fixed", frames_per_phoneme=FRAMES_PER_PHONEME)
+        voc_state = sw.make_vocoder_state(cfg, seed=4321)
+        blob = torch.from_numpy(packer.pack(dims, ac_state, voc_state)).cuda()
+        nbytes = torch.tensor([blob.numel()], dtype=torch.int64, device="cuda")
+    else:
+        nbytes = torch.zeros(1, dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.broadcast(nbytes, src=0)
+        if rank != 0:
+            blob = torch.empty(int(nbytes.item()), dtype=torch.uint8, device="cuda")
+        t0 = time.perf_counter()
+        dist.broadcast(blob, src=0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"[bench] weight blob {blob.numel() / 1e6:.1f} MB broadcast to {world} ranks in {(time.perf_counter() - t0) * 1e3:.1f} ms")
+    eng = Engine(dims, device=local_rank)
+    eng.load_weights(blob)
+    del blob
+
+    B, L = args.batch, PHONEMES
+    rng = np.random.Generator(np.random.PCG64(1000 + rank))
+    ids = torch.from_numpy(rng.integers(4, 131, size=(B, L)).astype(np.int64)).cuda()
+    lens = torch.full((B,), L, dtype=torch.int64, device="cuda")
+    spk = torch.tensor([1], dtype=torch.int64, device="cuda")
+    T = L * FRAMES_PER_PHONEME
+    pcm = torch.empty((B, T * hop), dtype=torch.int16, device="cuda")
+    mel_lens = torch.empty((B,), dtype=torch.int64, device="cuda")
+
+    def step():
+        _, _, t = eng.synthesize(ids, lens, spk, out_pcm=pcm, out_mel_lens=mel_lens)
+        return t
+
+    for _ in range(args.warmup):
+        t = step()
+        assert t == T, (t, T)
+    assert int(mel_lens.min().item()) == T and int(mel_lens.max().item()) == T
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats_k = eng.profile_read()
+    eng.profile_enable(False)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    samples_per_step = world * B * T * hop  # every rank synthesises B utterances of T valid frames
+    value = samples_per_step * args.steps / elapsed
+
+    if rank == 0:
+        # roofline of the dominant kernel: algorithmic FLOPs of its launches / sum of their HIP-event durations
+        stats_k.sort(key=lambda s: -s["ms"])
+        for s in stats_k:
+            tf = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
+            gbs = s["bytes"] / (s["ms"] * 1e-3) / 1e9 if s["ms"] > 0 else 0.0
+            log(f"[bench] {s['name']:<20} launches/step {s['launches'] / args.steps:7.1f}  ms/step {s['ms'] / args.steps:9.3f}  "
+                f"avg {s['ms'] / max(s['launches'], 1) * 1e3:9.1f} us  {tf:7.2f} TFLOP/s  {gbs:8.1f} GB/s (algorithmic)")
+        dom = stats_k[0]
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        kernel_ms = sum(s["ms"] for s in stats_k) / args.steps
+        roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
+                    "launches_per_step": dom["launches"] / args.steps,
+                    "all_conv_gemm_tflops": round(sum(s["flops"] for s in stats_k if s["name"].startswith("conv_gemm")) /
+                                                  (sum(s["ms"] for s in stats_k if s["name"].startswith("conv_gemm")) * 1e-3) / 1e12, 3),
+                    "kernel_ms_per_step": round(kernel_ms, 3)}
+        # host-inclusive variant (ids from host memory, PCM back to host memory): reported, never `value`
+        ids_h, lens_h, spk_h = ids.cpu().numpy(), lens.cpu().numpy(), spk.cpu().numpy()
+        pcm_h = np.empty((B, T * hop), np.int16)
+        eng.synthesize(ids_h, lens_h, spk_h, out_pcm=pcm_h)
+        th = time.perf_counter()
+        for _ in range(3):
+            eng.synthesize(ids_h, lens_h, spk_h, out_pcm=pcm_h)
+        host_rate = B * T * hop * 3 / (time.perf_counter() - th)
+        log(f"[bench] host-inclusive (pageable ids in, PCM out over PCIe): {host_rate:,.0f} samples/s per GPU")
+        out = {
+            "metric": "audio samples/sec (22.05 kHz, batch-32 per GPU, FastSpeech2 + HiFi-GAN inference)",
+            "value": value, "unit": "audio samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"B={B}/GPU fixed-length L={L} phonemes x {FRAMES_PER_PHONEME} frames = T={T} frames "
+                                   f"({T * hop} samples, {T * hop / dims.sample_rate:.2f} s) per utterance; default model_config "
+                                   "(6+6 FFT blocks H=384, HiFi-GAN V1), random-init weights",
+                       "sample_rate": dims.sample_rate, "global_batch": world * B, "parallelism": f"utterance-sharded x{world}"},
+            "real_time_factor": value / dims.sample_rate,
+            "host_inclusive_samples_per_s_per_gpu": host_rate,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, stats, ac_state, voc_state)
+            log(f"[bench] cpu_baseline: {out['cpu_baseline']}")
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

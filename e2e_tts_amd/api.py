@@ -1,0 +1,220 @@
+"""Drop-in mirrors of the reference's host loop: ``TTS`` (reference e2e_tts/src/api/utils.py:22-160) and the
+service wrapper ``Synthesizer`` (e2e_tts/src/api/inference.py:12-50).
+
+Same constructor arguments, attributes (``hop_length``, ``sample_rate``, ``max_wav_value``, ``speakers``,
+``config``, ``stats``, ``max_len``) and method signatures.  Differences, all deliberate:
+
+* one HIP engine holds both models, so the mel never leaves HBM between acoustic model and vocoder and the
+  only device->host traffic per batch is the int16 PCM (the reference copies fp32 audio, API/utils.py:145);
+* ``input_parse`` sorts with a *stable* descending sort (torch.sort(descending=True) at :84 leaves the order of
+  equal-length sentences unspecified; batches and audio are identical, only ties may be numbered differently);
+* text -> phoneme ids is pluggable (``text_to_sequence=``): the reference's g2p package is the next item of the
+  scope table and, as shipped, cannot run (cleaners.py:12,26-30 recurses with a bad kwarg);
+* no network call to a text normaliser (API/inference.py:28-33 swallows its failure anyway), no upload.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+import wave
+from datetime import datetime
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import packer
+from ._lib import Engine
+from .config import N_SYMBOLS, dims_from_config
+from .models import HifiGan, UnsupervisedFastSpeech2, _device_index
+
+
+def _load_state(path: str):
+    import torch
+    ckpt = torch.load(path, map_location="cpu")
+    return ckpt["state_dict"]
+
+
+class TTS:
+    def __init__(self, acoustic_path: str, vocoder_path: str, max_len: int = 300, device=None,
+                 text_to_sequence: Optional[Callable[[str], Sequence[int]]] = None, n_symbols: int = N_SYMBOLS,
+                 pos_table_rows: int = 4096):
+        import yaml
+        self.device = device
+        self._device_index = _device_index(device)
+        base = os.path.dirname(acoustic_path)
+        # the three side-car files written by save_information (reference tools_for_model.py:143-152)
+        self.config = yaml.load(open(os.path.join(base, "config.yaml"), "r"), Loader=yaml.FullLoader)
+        self.speakers = json.load(open(os.path.join(base, "speakers.json"), "r"))
+        self.stats = json.load(open(os.path.join(base, "stats.json"), "r"))
+        if self.config["models"]["fastspeech2"]["variance"]["duration_modelling"]["learn_alignment"] is not True:
+            raise NotImplementedError("SupervisedFastSpeech2 checkpoints are out of scope (reference API/utils.py:37-40)")
+        self._dims = dims_from_config(self.config, self.stats, len(self.speakers), n_symbols, pos_table_rows)
+        self._acoustic_state = _load_state(acoustic_path)
+        self._vocoder_state = _load_state(vocoder_path)
+        self.engine = Engine(self._dims, self._device_index)
+        self.engine.load_weights(packer.pack(self._dims, self._acoustic_state, self._vocoder_state))
+        self.hop_length = self.config["audio"]["stft"]["hop_length"]
+        self.sample_rate = self.config["audio"]["signal"]["sampling_rate"]
+        self.max_wav_value = 32768.0
+        self.max_len = max_len
+        self.text_to_sequence = text_to_sequence
+        self._acoustic = None
+        self._vocoder = None
+
+    # the reference exposes the two modules as attributes; build the stand-alone mirrors only on demand
+    @property
+    def acoustic(self) -> UnsupervisedFastSpeech2:
+        if self._acoustic is None:
+            m = UnsupervisedFastSpeech2(self._dims.n_symbols, len(self.speakers), self._dims.n_mel,
+                                        self.config["models"]["fastspeech2"], self.stats, device=self._device_index,
+                                        hop_length=self.hop_length, sampling_rate=self.sample_rate)
+            m.load_state_dict(self._acoustic_state)
+            self._acoustic = m.eval().to(self._device_index)
+        return self._acoustic
+
+    @property
+    def vocoder(self) -> HifiGan:
+        if self._vocoder is None:
+            v = HifiGan(self.config["models"]["hifigan"], device=self._device_index)
+            v.load_state_dict(self._vocoder_state)
+            self._vocoder = v.eval().to(self._device_index)
+        return self._vocoder
+
+    # ---- reference API/utils.py:64-80
+    def arrange_text(self, text: List[str]) -> List[str]:
+        arranged_text: List[str] = []
+        for line in text:
+            if round(len(line) / self.max_len) != 1:
+                pieces = line.split(" , ")
+                arranged_text.append(pieces[0])
+                for piece in pieces[1:]:
+                    if len(arranged_text[-1]) >= self.max_len:
+                        arranged_text.append(piece)
+                    else:
+                        arranged_text[-1] = " , ".join([arranged_text[-1], piece])
+            else:
+                arranged_text.append(line)
+        return arranged_text
+
+    @staticmethod
+    def pack_sequences(sequences: Sequence[Sequence[int]], max_len: int):
+        """The batching arithmetic of reference API/utils.py:84-104 on already-tokenised sequences.
+
+        Sort by length (descending, stable), then cut greedily into batches whose length sum stays <= max_len;
+        the sentence that overflows a batch opens the next one WITHOUT being counted in its total (the
+        reference's `s, total_lens = e, 0` at :96-99 -- reproduced, it decides the batch composition and the
+        padded-batch results depend on it).  Returns ([(ids [B, L] int64, lens [B] int64), ...], revert_indices).
+        """
+        lens = np.asarray([len(s) for s in sequences], dtype=np.int64)
+        order = np.argsort(-lens, kind="stable")
+        revert = np.argsort(order, kind="stable")
+        spans = []
+        s = e = total = 0
+        for i, n in enumerate(lens[order]):
+            if s == e or total + n <= max_len:
+                e = i + 1
+                total += int(n)
+            else:
+                spans.append((s, e))
+                s, total = e, 0
+        if not spans or spans[-1][1] != len(lens):
+            spans.append((s, len(lens)))
+        batches = []
+        for s, e in spans:
+            rows = [sequences[j] for j in order[s:e]]
+            L = max(len(r) for r in rows)
+            ids = np.zeros((len(rows), L), dtype=np.int64)  # pad_sequence(batch_first=True): zero padding
+            for r, row in enumerate(rows):
+                ids[r, :len(row)] = np.asarray(row, dtype=np.int64)
+            batches.append((ids, lens[order[s:e]].copy()))
+        return batches, revert
+
+    def input_parse(self, input_texts: List[str]):
+        """-> (list of [ids LongTensor [B, L], lens LongTensor [B]], revert_indices LongTensor) like the reference."""
+        import torch
+        if self.text_to_sequence is None:
+            raise RuntimeError("TTS was built without a text front-end: pass text_to_sequence=... or call inference_ids()")
+        seqs = [list(self.text_to_sequence(t)) for t in self.arrange_text(input_texts)]
+        batches, revert = self.pack_sequences(seqs, self.max_len)
+        return [[torch.from_numpy(i), torch.from_numpy(l)] for i, l in batches], torch.from_numpy(revert)
+
+    # ---- reference API/utils.py:108-117
+    def combine_audio(self, audios, lengths, distance: int) -> np.ndarray:
+        output_audio = []
+        for i, audio in enumerate(audios):
+            audio = np.asarray(audio)[: int(lengths[i]) * self.hop_length]
+            audio = audio * self.max_wav_value
+            output_audio.extend([audio, np.zeros(distance)])
+        return np.concatenate(output_audio).astype("int16")
+
+    def _combine_pcm(self, pcms: List[np.ndarray], lengths: List[int], distance: int) -> np.ndarray:
+        """Same result as combine_audio, from the int16 the GPU already produced (trunc(wav * 32768))."""
+        total = sum(int(n) * self.hop_length + distance for n in lengths)
+        out = np.zeros(total, dtype=np.int16)
+        pos = 0
+        for pcm, n in zip(pcms, lengths):
+            k = int(n) * self.hop_length
+            out[pos:pos + k] = pcm[:k]
+            pos += k + distance
+        return out
+
+    def inference_ids(self, sequences: Sequence[Sequence[int]], speaker_id: str, pitch_control: float = 1.0,
+                      energy_control: float = 1.0, duration_control: float = 1.0, silence_distance: float = 0.5) -> np.ndarray:
+        """TTS.inference from phoneme-id sequences (the part after text_to_sequence)."""
+        batches, revert = self.pack_sequences([list(s) for s in sequences], self.max_len)
+        spk = np.array([self.speakers[speaker_id]], dtype=np.int64)  # KeyError for an unknown speaker, as the reference
+        pcms, lengths = [], []
+        for ids, lens in batches:
+            pcm, mel_lens, T = self.engine.synthesize(ids, lens, spk, duration_control, pitch_control, energy_control)
+            pcms.extend(list(pcm))
+            lengths.extend(int(x) for x in mel_lens)
+        pcms = [pcms[i] for i in revert.tolist()]
+        lengths = [lengths[i] for i in revert.tolist()]
+        return self._combine_pcm(pcms, lengths, int(silence_distance * self.sample_rate))
+
+    def inference(self, texts: list, speaker_id: str, pitch_control: float = 1.0, energy_control: float = 1.0,
+                  duration_control: float = 1.0, silence_distance: float = 0.5) -> np.ndarray:
+        """reference API/utils.py:119-160 -> 1-D np.int16."""
+        if isinstance(texts, str):
+            texts = [texts]  # API/inference.py:39-40 passes a bare str, which the reference would iterate per character
+        if self.text_to_sequence is None:
+            raise RuntimeError("TTS was built without a text front-end: pass text_to_sequence=... or call inference_ids()")
+        seqs = [list(self.text_to_sequence(t)) for t in self.arrange_text(texts)]
+        generated_audio = self.inference_ids(seqs, speaker_id, pitch_control, energy_control, duration_control, silence_distance)
+        print(f"Audio Saved: {time.strftime('%H:%M:%S', time.gmtime(generated_audio.size / self.sample_rate))}")
+        return generated_audio
+
+
+def write_wav(path: str, audio: np.ndarray, samplerate: int) -> None:
+    """16-bit mono PCM WAV (what soundfile.write(path, int16 array, sr) produces at API/inference.py:47)."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(int(samplerate))
+        f.writeframes(np.ascontiguousarray(audio, dtype="<i2").tobytes())
+
+
+class Synthesizer:
+    """reference e2e_tts/src/api/inference.py:12-50."""
+
+    def __init__(self, acoustic_path: str, vocoder_path: str, output_dir: str = "outputs", **tts_kwargs) -> None:
+        self.model = TTS(acoustic_path=acoustic_path, vocoder_path=vocoder_path, **tts_kwargs)
+        os.makedirs(output_dir, exist_ok=True)
+        self.output_dir = output_dir
+
+    def tts_to_file(self, text: str, file_path: str, speed: float = 1):
+        return self.synthesis(text, file_path, speed)
+
+    def synthesis(self, text: str, save_filepath: str = None, speed: float = 1, speaker_id: str = "hn_minhphuong", sr: int = 22050):
+        assert len(text) > 0
+        if not save_filepath:
+            save_filepath = os.path.join(self.output_dir, datetime.now().strftime("%m_%d_%Y_%H_%M_%S") + ".wav")
+        audio = self.model.inference(texts=[text], speaker_id=speaker_id, pitch_control=1.0, energy_control=1.0,
+                                     duration_control=1.0, silence_distance=0.5)
+        write_wav(save_filepath, audio, sr)
+        if speed != 1:
+            raise NotImplementedError("speed != 1 shells out to ffmpeg atempo in the reference (API/utils.py:163-172); "
+                                      "out of scope here -- use duration_control for tempo")
+        return save_filepath

@@ -75,7 +75,7 @@ struct e2etts_engine {
   // weights
   DevBuf blob;
   std::map<std::string, std::pair<const float*, uint64_t>> tensors;
-  bool loaded = false;
+  bool ac_loaded = false, voc_loaded = false;
   std::vector<FFTLayer> enc, dec;
   Predictor dur, pitch, energy;
   const float *emb = nullptr, *enc_pos = nullptr, *dec_pos = nullptr, *pos_regen = nullptr, *spk_emb = nullptr;
@@ -281,7 +281,7 @@ int bind_pred(e2etts_engine* e, const char* name, int layers, int kernel, int ch
   return E2ETTS_OK;
 }
 
-int bind_all(e2etts_engine* e) {
+int bind_acoustic(e2etts_engine* e) {
   const auto& c = e->cfg;
   const uint64_t H = c.hidden;
   RET(get_tensor(e, "enc.emb", (uint64_t)(c.n_symbols + 1) * H, &e->emb));
@@ -313,6 +313,11 @@ int bind_all(e2etts_engine* e) {
     RET(get_tensor(e, p + "w", cout * c.postnet_kernel * cin, &e->postnet[i].w));
     RET(get_tensor(e, p + "b", cout, &e->postnet[i].b));
   }
+  return E2ETTS_OK;
+}
+
+int bind_vocoder(e2etts_engine* e) {
+  const auto& c = e->cfg;
   const uint64_t C0 = c.voc_init_ch;
   RET(get_tensor(e, "voc.pre.w", C0 * 7 * c.n_mel, &e->voc_pre.w));
   RET(get_tensor(e, "voc.pre.b", C0, &e->voc_pre.b));
@@ -445,7 +450,7 @@ __global__ void lens_to_i32_kernel(const int64_t* in, int32_t* out, int B, int L
 int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int B, int L, const int64_t* speaker,
                   int n_spk_ids, float d_control, float p_control, float e_control) {
   const auto& c = e->cfg;
-  if (!e->loaded) return e->fail(E2ETTS_ESTATE, "weights not loaded");
+  if (!e->ac_loaded) return e->fail(E2ETTS_ESTATE, "acoustic weights not loaded");
   if (!ids || !lens || !speaker) return e->fail(E2ETTS_EINVAL, "ids / lens / speaker must not be NULL");
   if (B <= 0 || L <= 0) return e->fail(E2ETTS_EINVAL, "B and L must be positive (got B=%d L=%d)", B, L);
   if (n_spk_ids != 1 && n_spk_ids != B) return e->fail(E2ETTS_EINVAL, "speaker must hold 1 or B ids");
@@ -603,7 +608,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
 // HifiGan.forward (V/generator.py:37-53) on channels-last mel [B, T, n_mel] already in HBM
 int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want_wav, bool want_pcm) {
   const auto& c = e->cfg;
-  if (!e->loaded) return e->fail(E2ETTS_ESTATE, "weights not loaded");
+  if (!e->voc_loaded) return e->fail(E2ETTS_ESTATE, "vocoder weights not loaded");
   if (B <= 0 || T <= 0) return e->fail(E2ETTS_EINVAL, "B and T must be positive");
   // largest activation of any stage, in floats per utterance
   long long len = T, ch = c.voc_init_ch;
@@ -758,7 +763,7 @@ int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
     return e->fail(E2ETTS_EINVAL, "corrupt blob directory");
   std::vector<BlobEntry> dir(h.n_entries);
   HIPCHK(e, hipMemcpy(dir.data(), (const char*)blob + sizeof h, dir_bytes, hipMemcpyDefault));
-  e->loaded = false;
+  e->ac_loaded = e->voc_loaded = false;
   RET(ensure(e, e->blob, nbytes));
   HIPCHK(e, hipMemcpyAsync(e->blob.p, blob, nbytes, hipMemcpyDefault, e->stream));
   e->tensors.clear();
@@ -768,9 +773,14 @@ int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
       return e->fail(E2ETTS_EINVAL, "tensor '%s' lies outside the blob", en.name);
     e->tensors[en.name] = {reinterpret_cast<const float*>((const char*)e->blob.p + en.offset), en.numel};
   }
-  RET(bind_all(e));
+  // a blob may carry the acoustic model, the vocoder, or both (the reference loads them from two checkpoints)
+  const bool has_ac = e->tensors.count("enc.emb") != 0, has_voc = e->tensors.count("voc.pre.w") != 0;
+  if (!has_ac && !has_voc) return e->fail(E2ETTS_EKEY, "blob holds neither acoustic ('enc.emb') nor vocoder ('voc.pre.w') tensors");
+  if (has_ac) RET(bind_acoustic(e));
+  if (has_voc) RET(bind_vocoder(e));
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  e->loaded = true;
+  e->ac_loaded = has_ac;
+  e->voc_loaded = has_voc;
   return E2ETTS_OK;
 }
 

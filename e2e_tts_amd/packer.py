@@ -26,7 +26,7 @@ from __future__ import annotations
 import math
 import struct
 from collections import OrderedDict
-from typing import Dict, Mapping
+from typing import Dict, Mapping, Optional
 
 import numpy as np
 
@@ -94,21 +94,31 @@ def polyphase_upsampler(w: np.ndarray, b: np.ndarray, stride: int):
     return out.reshape(s * cout, 3 * cin), np.tile(b, s).astype(np.float32)
 
 
-def pack_tensors(dims: EngineDims, acoustic: Mapping[str, object], vocoder: Mapping[str, object]) -> "OrderedDict[str, np.ndarray]":
-    """Engine tensor name -> fp32 array (see bind_all() in csrc/engine.hip for the consumer)."""
-    A = {k: _np(v) for k, v in acoustic.items()}
-    V = {k: _np(v) for k, v in vocoder.items()}
-    H = dims.hidden
+def pack_tensors(dims: EngineDims, acoustic: Optional[Mapping[str, object]], vocoder: Optional[Mapping[str, object]]) -> "OrderedDict[str, np.ndarray]":
+    """Engine tensor name -> fp32 array (consumers: bind_acoustic() / bind_vocoder() in csrc/engine.hip).
+    Either state dict may be None: the blob then carries only the other model."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    if acoustic is not None:
+        _pack_acoustic(dims, {k: _np(v) for k, v in acoustic.items()}, out)
+    if vocoder is not None:
+        _pack_vocoder(dims, {k: _np(v) for k, v in vocoder.items()}, out)
+    if not out:
+        raise ValueError("nothing to pack: both state dicts are None")
+    return OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32)) for k, v in out.items())
 
-    def need(sd, key, shape=None):
-        if key not in sd:
-            raise KeyError(f"checkpoint has no tensor {key!r}")
-        t = sd[key]
-        if shape is not None and tuple(t.shape) != tuple(shape):
-            raise ValueError(f"{key}: shape {tuple(t.shape)} != expected {tuple(shape)}")
-        return t.astype(np.float32) if t.dtype.kind == "f" else t
 
+def _need(sd, key, shape=None):
+    if key not in sd:
+        raise KeyError(f"checkpoint has no tensor {key!r}")
+    t = sd[key]
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{key}: shape {tuple(t.shape)} != expected {tuple(shape)}")
+    return t.astype(np.float32) if t.dtype.kind == "f" else t
+
+
+def _pack_acoustic(dims: EngineDims, A, out) -> None:
+    H = dims.hidden
+    need = _need
     out["enc.emb"] = need(A, "encoder.src_word_emb.weight", (dims.n_symbols + 1, H))
     out["enc.pos"] = need(A, "encoder.position_enc", (1, dims.max_seq_len + 1, H))[0]
     out["dec.pos"] = need(A, "decoder.position_enc", (1, dims.max_seq_len + 1, H))[0]
@@ -162,6 +172,10 @@ def pack_tensors(dims: EngineDims, acoustic: Mapping[str, object], vocoder: Mapp
         out[f"post.{i}.w"] = conv_rows(wf)
         out[f"post.{i}.b"] = bf
 
+
+def _pack_vocoder(dims: EngineDims, V, out) -> None:
+    need = _need
+
     def voc_weight(prefix):
         if prefix + ".weight_v" in V:
             return fold_weight_norm(need(V, prefix + ".weight_g"), need(V, prefix + ".weight_v")), need(V, prefix + ".bias")
@@ -181,7 +195,6 @@ def pack_tensors(dims: EngineDims, acoustic: Mapping[str, object], vocoder: Mapp
                     out[f"voc.rb.{idx}.{short}.{m}.w"], out[f"voc.rb.{idx}.{short}.{m}.b"] = conv_rows(w), b
     w, b = voc_weight("conv_post")
     out["voc.post.w"], out["voc.post.b"] = conv_rows(w), b
-    return OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32)) for k, v in out.items())
 
 
 def build_blob(tensors: Mapping[str, np.ndarray]) -> np.ndarray:
@@ -209,5 +222,5 @@ def build_blob(tensors: Mapping[str, np.ndarray]) -> np.ndarray:
     return blob
 
 
-def pack(dims: EngineDims, acoustic: Mapping[str, object], vocoder: Mapping[str, object]) -> np.ndarray:
+def pack(dims: EngineDims, acoustic: Optional[Mapping[str, object]], vocoder: Optional[Mapping[str, object]]) -> np.ndarray:
     return build_blob(pack_tensors(dims, acoustic, vocoder))

@@ -1,0 +1,89 @@
+"""GPU tests (-m gpu) of the drop-in classes: TTS built from checkpoint files laid out as the reference writes them
+(statedict.pt + config.yaml + speakers.json + stats.json), and the stand-alone model mirrors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, states_for
+from e2e_tts_amd import config as cfgmod, synth_weights as sw
+
+pytestmark = pytest.mark.gpu
+
+
+def write_checkpoints(tmp_path, cfg, ac, voc):
+    import torch
+    import yaml
+    d = tmp_path / "exps" / "acoustic"
+    v = tmp_path / "exps" / "vocoder"
+    d.mkdir(parents=True)
+    v.mkdir(parents=True)
+    torch.save({"state_dict": sw.to_torch(ac), "optimizer": {}}, d / "statedict.pt")
+    torch.save({"state_dict": sw.to_torch(voc)}, v / "statedict.pt")
+    full = dict(cfg)
+    full["train"] = {"seed": 1234}
+    yaml.safe_dump(full, open(d / "config.yaml", "w"))
+    json.dump(cfgmod.DEFAULT_SPEAKERS, open(d / "speakers.json", "w"))
+    json.dump(cfgmod.DEFAULT_STATS, open(d / "stats.json", "w"))
+    return str(d / "statedict.pt"), str(v / "statedict.pt")
+
+
+def test_tts_from_checkpoint_files_matches_oracle(tmp_path):
+    from e2e_tts_amd.api import TTS, Synthesizer
+    from e2e_tts_amd.packer import variance_position_table
+    from oracle import ref_numpy as orc
+    cfg = cfgmod.tiny_config()
+    stats = cfgmod.DEFAULT_STATS
+    ac = sw.make_acoustic_state(cfg, stats, 4, seed=7, mode="varied")
+    voc = sw.make_vocoder_state(cfg, seed=8)
+    apath, vpath = write_checkpoints(tmp_path, cfg, ac, voc)
+    tts = TTS(apath, vpath, max_len=60)
+    assert tts.hop_length == 256 and tts.sample_rate == 22050 and tts.max_wav_value == 32768.0
+    rng = np.random.Generator(np.random.PCG64(11))
+    seqs = [list(rng.integers(4, 131, n)) for n in (25, 9, 31, 31, 14, 3)]
+    pcm = tts.inference_ids(seqs, "spk_c", pitch_control=1.1, energy_control=0.9, duration_control=1.0, silence_distance=0.01)
+    # oracle: same batches (the product's pack_sequences is pinned against the reference fixture on CPU)
+    batches, revert = TTS.pack_sequences(seqs, 60)
+    assert len(batches) >= 2
+    o_ac = orc.AcousticOracle(ac, cfg, stats, var_pos_table=variance_position_table(4096, 64))
+    o_voc = orc.VocoderOracle(voc, cfg)
+    ref = orc.synthesize(o_ac, o_voc, batches, cfgmod.DEFAULT_SPEAKERS["spk_c"], revert, int(0.01 * 22050), 256,
+                         controls=(1.1, 0.9, 1.0))
+    assert pcm.dtype == np.int16 and pcm.shape == ref.shape
+    close = np.abs(pcm.astype(np.int32) - ref.astype(np.int32)) <= 1
+    assert close.mean() >= 0.999, close.mean()
+    with pytest.raises(KeyError):
+        tts.inference_ids(seqs, "nobody")
+    # text path + wav writer through the service wrapper
+    syn = Synthesizer(apath, vpath, output_dir=str(tmp_path / "out"), max_len=60,
+                      text_to_sequence=lambda t: [4 + (ord(c) % 127) for c in t])
+    path = syn.synthesis("xin chao , viet nam", save_filepath=str(tmp_path / "out" / "a.wav"), speaker_id="spk_b")
+    import wave
+    with wave.open(path) as f:
+        assert f.getframerate() == 22050 and f.getsampwidth() == 2 and f.getnframes() > 22050 // 2
+
+
+def test_model_mirrors_match_reference_fixture():
+    import torch
+    from e2e_tts_amd.models import HifiGan, UnsupervisedFastSpeech2
+    g = load_golden("tiny_b3")
+    cfg, ac, voc = states_for(g, "tiny_b3")
+    m = UnsupervisedFastSpeech2(n_symbols=131, n_speakers=4, n_channels=80, config=cfg["models"]["fastspeech2"],
+                                stats=cfgmod.DEFAULT_STATS)
+    m.load_state_dict(sw.to_torch(ac))
+    m.eval().to(torch.device("cuda", 0))
+    (mel, mel_post, dur), mel_lens = m.inference(speaker=torch.tensor([int(g["speaker"])]), texts=torch.from_numpy(g["ids"]),
+                                                 txt_lens=torch.from_numpy(g["lens"]), max_txt_len=g["ids"].shape[1])
+    assert mel_post.is_cuda and tuple(mel_post.shape) == g["mel_post"].shape
+    np.testing.assert_array_equal(dur.cpu().numpy(), g["dur"])
+    np.testing.assert_array_equal(mel_lens.cpu().numpy(), g["mel_lens"])
+    assert np.abs(mel_post.cpu().numpy() - g["mel_post"]).mean() < 1e-5
+    v = HifiGan(cfg["models"]["hifigan"])
+    v.load_state_dict(sw.to_torch(voc))
+    v.eval().to(torch.device("cuda", 0))
+    v.remove_weight_norm()
+    wav = v(mel_post.transpose(1, 2)).squeeze(1)   # exactly how TTS.inference calls it (API/utils.py:144)
+    assert np.abs(wav.cpu().numpy() - g["wav"]).mean() < 1e-5
+    with pytest.raises(RuntimeError):
+        m.to("cpu")

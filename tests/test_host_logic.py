@@ -1,0 +1,153 @@
+"""CPU tests of the product's host side (no GPU, no oracle in the product path): text arrangement / batching /
+PCM assembly against the fixture produced by the reference's own methods, the weight packer, the C ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from e2e_tts_amd import config as cfgmod, packer, synth_weights as sw
+from e2e_tts_amd.api import TTS
+
+
+def bare_tts(max_len=300, hop=256):
+    t = TTS.__new__(TTS)  # host-logic methods only: no checkpoint, no engine
+    t.max_len, t.hop_length, t.max_wav_value, t.sample_rate = max_len, hop, 32768.0, 22050
+    return t
+
+
+def toy_tokenizer(txt):
+    return [4 + (ord(c) % 127) for c in txt]
+
+
+def test_arrange_and_batch_match_reference_fixture():
+    g = load_golden("host_loop")
+    t = bare_tts()
+    texts = [str(x) for x in g["texts"]]
+    arranged = t.arrange_text(list(texts))
+    assert arranged == [str(x) for x in g["arranged"]]
+    t.text_to_sequence = toy_tokenizer
+    batches, revert = t.input_parse(list(texts))
+    np.testing.assert_array_equal(revert.numpy(), g["revert"])
+    assert len(batches) == int(g["n_batches"])
+    for i, (ids, lens) in enumerate(batches):
+        np.testing.assert_array_equal(ids.numpy(), g[f"ids{i}"])
+        np.testing.assert_array_equal(lens.numpy(), g[f"lens{i}"])
+
+
+def test_token_budget_quirk_matches_reference_fixture():
+    g = load_golden("host_loop")
+    lens = g["stress_lens"]
+    batches, revert = TTS.pack_sequences([[5] * int(n) for n in lens], 300)
+    np.testing.assert_array_equal([len(l) for _, l in batches], g["stress_batch_sizes"])
+    np.testing.assert_array_equal([int(l[0]) for _, l in batches], g["stress_batch_first_len"])
+    order = np.argsort(revert)
+    ref_order = np.argsort(g["stress_revert"])
+    np.testing.assert_array_equal(lens[order], lens[ref_order])  # equal up to the tie order torch.sort leaves open
+
+
+def test_combine_audio_matches_reference_fixture():
+    g = load_golden("host_loop")
+    t = bare_tts()
+    audios = [g["ca_audio0"], g["ca_audio1"], g["ca_audio2"]]
+    pcm = t.combine_audio(audios, g["ca_lengths"], int(g["ca_distance"]))
+    np.testing.assert_array_equal(pcm, g["ca_pcm"])
+    # the GPU emits (int16)(int32)(wav * 32768); assembling those must give the same stream
+    gpu_like = [(a * np.float32(32768.0)).astype(np.int32).astype(np.int16) for a in audios]
+    np.testing.assert_array_equal(t._combine_pcm(gpu_like, list(g["ca_lengths"]), int(g["ca_distance"])), g["ca_pcm"])
+
+
+def test_empty_and_single_inputs():
+    batches, revert = TTS.pack_sequences([[7, 8, 9]], 300)
+    assert len(batches) == 1 and batches[0][0].shape == (1, 3) and revert.tolist() == [0]
+    batches, _ = TTS.pack_sequences([[5] * 400, [5] * 10], 300)  # an over-budget sentence still forms a batch
+    assert [len(l) for _, l in batches][0] == 1
+    t = bare_tts()
+    assert t.arrange_text([]) == []
+
+
+def test_polyphase_upsampler_equals_conv_transpose():
+    from oracle import ref_numpy as orc
+    rng = np.random.Generator(np.random.PCG64(3))
+    for s, cin, cout in ((8, 12, 8), (2, 8, 4)):
+        w = rng.standard_normal((cin, cout, 2 * s)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        x = rng.standard_normal((2, cin, 13)).astype(np.float32)
+        ref = orc.conv_transpose1d(x, w, b, s, s // 2)                      # [B, cout, 13 * s]
+        w3, b3 = packer.polyphase_upsampler(w, b, s)                       # [s*cout, 3*cin]
+        y = orc.conv1d(x, w3.reshape(s * cout, 3, cin).transpose(0, 2, 1), b3, padding=1)  # [B, s*cout, 13]
+        y = y.reshape(2, s, cout, 13).transpose(0, 2, 3, 1).reshape(2, cout, 13 * s)
+        np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
+
+
+def test_blob_roundtrip_and_batchnorm_fold():
+    cfg = cfgmod.tiny_config()
+    stats = cfgmod.DEFAULT_STATS
+    ac = sw.make_acoustic_state(cfg, stats, 4, mode="varied")
+    voc = sw.make_vocoder_state(cfg)
+    dims = cfgmod.dims_from_config(cfg, stats, 4)
+    tensors = packer.pack_tensors(dims, ac, voc)
+    blob = packer.build_blob(tensors)
+    magic, version, n, data_off, total = np.frombuffer(blob[:8], "S8")[0], *np.frombuffer(blob[8:16], "<u4"), *np.frombuffer(blob[16:32], "<u8")
+    assert magic == b"E2ETTSW1" and version == 1 and n == len(tensors) and total == blob.size and data_off % 256 == 0
+    for i, (name, t) in enumerate(tensors.items()):
+        ent = blob[32 + 80 * i: 32 + 80 * (i + 1)]
+        assert ent[:64].tobytes().rstrip(b"\0").decode() == name
+        off, numel = np.frombuffer(ent[64:80], "<u8")
+        assert off % 256 == 0 and numel == t.size
+        np.testing.assert_array_equal(blob[off:off + 4 * numel].view(np.float32), t.reshape(-1))
+    # BN fold: conv + eval BatchNorm == folded conv (postnet layer 0)
+    from oracle import ref_numpy as orc
+    rng = np.random.Generator(np.random.PCG64(4))
+    x = rng.standard_normal((1, 80, 9)).astype(np.float32)
+    p = "postnet.convolutions.0"
+    y = orc.conv1d(x, ac[p + ".0.conv.weight"], ac[p + ".0.conv.bias"], padding=2)
+    y = (y - ac[p + ".1.running_mean"][None, :, None]) / np.sqrt(ac[p + ".1.running_var"][None, :, None] + 1e-5)
+    y = y * ac[p + ".1.weight"][None, :, None] + ac[p + ".1.bias"][None, :, None]
+    k = dims.postnet_kernel
+    wf = tensors["post.0.w"].reshape(-1, k, 80).transpose(0, 2, 1)
+    np.testing.assert_allclose(orc.conv1d(x, wf, tensors["post.0.b"], padding=2), y, rtol=0, atol=2e-5)
+    # halves
+    assert "voc.pre.w" not in packer.pack_tensors(dims, ac, None) and "enc.emb" not in packer.pack_tensors(dims, None, voc)
+
+
+def test_config_rejects_unimplemented_variants():
+    cfg = cfgmod.default_config()
+    cfg["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"
+    with pytest.raises(NotImplementedError):
+        cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4)
+    cfg = cfgmod.default_config()
+    cfg["models"]["hifigan"]["resblock"] = 2
+    with pytest.raises(NotImplementedError):
+        cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4)
+    cfg = cfgmod.default_config()
+    cfg["audio"]["stft"]["hop_length"] = 300
+    with pytest.raises(ValueError):
+        cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/e2etts.h declares."""
+    from e2e_tts_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    header = open(os.path.join(ROOT, "include", "e2etts.h")).read()
+    declared = sorted(set(re.findall(r"\b(e2etts_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(_lib.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert ctypes.sizeof(cfgmod.CEngineConfig) == 4 * (23 + 8 + 8 + 1 + 4 + 1 + 16 + 3) + 8
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from e2e_tts_amd._lib import Engine
+    dims = cfgmod.dims_from_config(cfgmod.tiny_config(), cfgmod.DEFAULT_STATS, 4)
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        Engine(dims, 0)

@@ -9,13 +9,19 @@
 // Mapping (channels-last activations [B, T, C], weights [Cout, KW*Cin] tap-major):
 //   M = time positions of one utterance, N = Cout, K = KW * Cin.
 //   D[t][n] += A[t][k] * B[k][n] with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD).
-// A workgroup (4 wavefronts of 64) owns a BM x BN output tile.  For each 32-channel chunk of Cin it stages
-// ONE activation slab of (BM + dil*(KW-1)) rows in LDS -- the taps of a dilated convolution are row-shifted
-// views of that slab, so the input is read from HBM/L2 once per chunk, not once per tap -- and streams the
-// per-tap weight tiles through a double-buffered LDS tile, prefetched into registers behind the MFMAs.
-// LDS rows are 36 floats (32 + 4 pad): a ds_read_b128 of 16 consecutive rows then covers all 64 banks once.
-// Operand fragments are read as float4 = 4 consecutive k; lane half h supplies k = 8q + 4h + r to MFMA r,
-// for both operands, so the k order inside an 8-wide group is permuted identically for A and B.
+//
+// Structure.  A workgroup (4 wavefronts of 64) walks a run of consecutive BM x BN output tiles of one utterance
+// (persistent over M).  The unit of staging is a WORK ITEM = (tile, 32-channel chunk of Cin): ONE activation slab
+// of BM + dil*(KW-1) rows goes to LDS -- the taps of a dilated convolution are row-shifted views of that slab, so
+// the input is read once per chunk, not once per tap -- and the KW per-tap weight tiles stream through a
+// double-buffered LDS tile.  Both streams are software-pipelined through registers: the next weight tile is
+// fetched one tap ahead and the next slab (next chunk, or the next tile's first chunk) one work item ahead,
+// so the global-load latency sits behind MFMAs instead of in front of them; the loads of the next tile also fly
+// during the epilogue.  LDS rows are 36 floats (32 + 4 pad): a ds_read_b128 of 16 consecutive rows covers all 64
+// banks once.  Operand fragments are float4 = 4 consecutive k; lane half h supplies k = 8q + 4h + r to MFMA r for
+// both operands, so the k order inside an 8-wide group is permuted identically for A and B.
+// Epilogue: accumulators are transposed through a wave-private LDS patch (carved from the idle slab) so that
+// bias / residual / accumulate reads and the result store are float4, 256 B contiguous per 16 lanes.
 #include "kernels.h"
 
 namespace e2etts {
@@ -36,12 +42,22 @@ __device__ __forceinline__ float4 lrelu4(float4 v, float slope) {
   return v;
 }
 
+__device__ __forceinline__ float act1(float v, int act, float slope) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_TANH) return tanhf(v);
+  if (act == ACT_LRELU) return v >= 0.f ? v : v * slope;
+  return v;
+}
+
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
   constexpr int NWN = BN / WN;
   constexpr int MT = WM / 32, NT = WN / 32;
   static_assert((BM / WM) * NWN == 4, "4 wavefronts per workgroup");
-  constexpr int BROWS = BN / 32;  // B-tile rows staged per thread
+  constexpr int BROWS = BN / 32;                      // weight-tile rows staged per thread
+  constexpr int AROWS = (BM + MAX_HALO + 31) / 32;    // slab rows staged per thread (upper bound)
+  constexpr int ELD = WN + 4;                         // epilogue patch row stride (floats)
+  static_assert(4 * 16 * ELD <= BM * LDK, "epilogue patches must fit in the slab");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int halo = p.dil * (p.KW - 1);
@@ -56,10 +72,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
 
   const int b = blockIdx.z;
-  const int t0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+  const int mtiles = (p.T + BM - 1) / BM;
+  const int tile0 = blockIdx.x * tiles_per_block;
+  const int ntile = min(tiles_per_block, mtiles - tile0);
   const float* in_b = p.in + (long long)b * p.in_bs;
   const int KC = p.KW * p.Cin;
+  const int nchunk = (p.Cin + BK - 1) / BK;
+  const int nitem = ntile * nchunk;
+  const int niter = nitem * p.KW;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -69,12 +90,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  const int nchunk = (p.Cin + BK - 1) / BK;
-  const int niter = nchunk * p.KW;
   float4 breg[BROWS];
+  float4 areg[AROWS];
 
-  auto load_b = [&](int it) {
-    const int chunk = it / p.KW, j = it - chunk * p.KW;
+  auto load_b = [&](int chunk, int j) {
     const int c = chunk * BK + lc4;
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
@@ -89,28 +108,139 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(dst + (lrow + i * 32) * LDK + lc4) = breg[i];
   };
-
-  load_b(0);
-  store_b(0);
-  int cur = 0;
-  for (int it = 0; it < niter; ++it) {
-    const int chunk = it / p.KW, j = it - chunk * p.KW;
-    if (j == 0) {
-      if (it != 0) __syncthreads();  // every wave is done reading the previous slab
-      const int c = chunk * BK + lc4;
-      const bool cok = c < p.Cin;
-      for (int r = lrow; r < arows; r += 32) {
-        const int t = t0 - p.pad + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cok && t >= 0 && t < p.T) {
-          v = *reinterpret_cast<const float4*>(in_b + (long long)t * p.in_ld + c);
-          if (p.in_slope != 1.0f) v = lrelu4(v, p.in_slope);
-        }
+  auto load_a = [&](int tile, int chunk) {
+    const int c = chunk * BK + lc4;
+    const bool cok = c < p.Cin;
+    const int tbase = tile * BM - p.pad;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int r = lrow + i * 32;
+      const int t = tbase + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < arows && cok && t >= 0 && t < p.T) v = *reinterpret_cast<const float4*>(in_b + (long long)t * p.in_ld + c);
+      areg[i] = v;
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int r = lrow + i * 32;
+      if (r < arows) {
+        float4 v = areg[i];
+        if (p.in_slope != 1.0f) v = lrelu4(v, p.in_slope);
         *reinterpret_cast<float4*>(As + r * LDK + lc4) = v;
       }
     }
-    if (it + 1 < niter) load_b(it + 1);  // global loads in flight behind the MFMAs below
-    __syncthreads();
+  };
+
+  // Epilogue of one output tile.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+  const bool vec_ok = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && ((p.out_bs & 3) == 0) && (((uintptr_t)p.out & 15) == 0) &&
+                      (!p.res || ((p.res_ld % 4 == 0) && ((p.res_bs & 3) == 0) && (((uintptr_t)p.res & 15) == 0))) &&
+                      (!p.bias || (((uintptr_t)p.bias & 15) == 0));
+  const int len = p.lens ? p.lens[b] : p.T;
+  float* out_b = p.out + (long long)b * p.out_bs;
+  const float* res_b = p.res ? p.res + (long long)b * p.res_bs : nullptr;
+  auto epilogue = [&](int tile) {
+    const int t0 = tile * BM;
+    if (vec_ok) {
+      float* patch = As + wave * (16 * ELD);  // wave-private: no workgroup barrier between its write and read
+      constexpr int LPR = WN / 4;             // lanes per row when reading float4
+      constexpr int RPP = 64 / LPR;           // rows per pass
+      const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+      const int col = n0 + wn * WN + pc4;
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias && col < p.Cout) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          __builtin_amdgcn_sched_barrier(0);  // keep the passes apart: hoisting their loads together costs ~100 VGPRs
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+              const int r = hh * 8 + rr;
+              const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;  // 0..15 inside this half
+              patch[row * ELD + n * 32 + li] = acc[m][n][r];
+            }
+#pragma unroll
+          for (int ps = 0; ps < 16 / RPP; ++ps) {
+            const int row = ps * RPP + prow;
+            const int t = t0 + wm * WM + m * 32 + hh * 16 + row;
+            float4 v = *reinterpret_cast<const float4*>(patch + row * ELD + pc4);
+            if (t < p.T && col < p.Cout) {
+              v.x = act1(v.x + bias4.x, p.act, p.act_slope);
+              v.y = act1(v.y + bias4.y, p.act, p.act_slope);
+              v.z = act1(v.z + bias4.z, p.act, p.act_slope);
+              v.w = act1(v.w + bias4.w, p.act, p.act_slope);
+              if (res_b) {
+                const float4 rv = *reinterpret_cast<const float4*>(res_b + (long long)t * p.res_ld + col);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+              }
+              if (t >= len) v = make_float4(0.f, 0.f, 0.f, 0.f);
+              float4* o = reinterpret_cast<float4*>(out_b + (long long)t * p.out_ld + col);
+              if (p.accumulate) {
+                const float4 ov = *o;
+                v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+              }
+              if (p.out_div != 1.0f) {
+                v.x = v.x / p.out_div; v.y = v.y / p.out_div; v.z = v.z / p.out_div; v.w = v.w / p.out_div;
+              }
+              *o = v;
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int col = n0 + wn * WN + n * 32 + li;
+        if (col >= p.Cout) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t = t0 + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (t >= p.T) continue;
+            float v = act1(acc[m][n][r] + bias, p.act, p.act_slope);
+            if (res_b) v += res_b[(long long)t * p.res_ld + col];
+            if (t >= len) v = 0.f;
+            float* o = out_b + (long long)t * p.out_ld + col;
+            if (p.accumulate) v += *o;
+            if (p.out_div != 1.0f) v = v / p.out_div;
+            *o = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  };
+
+  load_a(tile0, 0);
+  store_a();
+  load_b(0, 0);
+  store_b(0);
+  int cur = 0;
+  int item = 0, j = 0;  // it = item * KW + j
+  for (int it = 0; it < niter; ++it) {
+    const int tl = item / nchunk, chunk = item - tl * nchunk;
+    const bool last_tap = j == p.KW - 1;
+    const bool more_items = item + 1 < nitem;
+    if (last_tap && more_items) {  // next slab: next chunk of this tile, or chunk 0 of the next tile
+      const int nchk = chunk + 1 == nchunk ? 0 : chunk + 1;
+      load_a(tile0 + tl + (nchk == 0 ? 1 : 0), nchk);
+    }
+    if (it + 1 < niter) {  // next weight tile: next tap, or tap 0 of the next item's chunk
+      if (!last_tap) load_b(chunk, j + 1);
+      else load_b(chunk + 1 == nchunk ? 0 : chunk + 1, 0);
+    }
+    __syncthreads();  // slab + Bs[cur] visible
 
     const float* a_base = As + (wm * WM + li + j * p.dil) * LDK + lh * 4;
     const float* b_base = Bs + cur * (BN * LDK) + (wn * WN + li) * LDK + lh * 4;
@@ -133,34 +263,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
     if (it + 1 < niter) store_b(cur ^ 1);  // that buffer was last read before this iteration's barrier
     cur ^= 1;
-  }
-
-  // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  const int len = p.lens ? p.lens[b] : p.T;
-  float* out_b = p.out + (long long)b * p.out_bs;
-  const float* res_b = p.res ? p.res + (long long)b * p.res_bs : nullptr;
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = n0 + wn * WN + n * 32 + li;
-    if (col >= p.Cout) continue;
-    const float bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int t = t0 + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (t >= p.T) continue;
-        float v = acc[m][n][r] + bias;
-        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == ACT_TANH) v = tanhf(v);
-        else if (p.act == ACT_LRELU) v = v >= 0.f ? v : v * p.act_slope;
-        if (res_b) v += res_b[(long long)t * p.res_ld + col];
-        if (t >= len) v = 0.f;
-        float* o = out_b + (long long)t * p.out_ld + col;
-        if (p.accumulate) v += *o;
-        if (p.out_div != 1.0f) v = v / p.out_div;
-        *o = v;
+    if (last_tap) {
+      const bool tile_done = chunk == nchunk - 1;
+      if (tile_done || more_items) __syncthreads();  // every wave is done reading the slab
+      if (tile_done) {
+        epilogue(tile0 + tl);
+        if (more_items) __syncthreads();  // patches read back before the slab is overwritten
       }
+      if (more_items) store_a();
+      j = 0;
+      ++item;
+    } else {
+      ++j;
     }
   }
 }
@@ -170,8 +284,15 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
   const int halo = p.dil * (p.KW - 1);
   const size_t lds = (size_t)((BM + halo) * LDK + 2 * BN * LDK) * sizeof(float);
   if (lds > 64 * 1024) return "conv_gemm: LDS tile exceeds 64 KiB";
-  dim3 grid((p.T + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.B);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
+  const int mtiles = (p.T + BM - 1) / BM;
+  const int ntiles = (p.Cout + BN - 1) / BN;
+  // Persistent over M: enough workgroups for ~8 per CU, each walking up to 8 consecutive tiles.
+  const long long total = (long long)mtiles * ntiles * p.B;
+  int tpb = (int)(total / (256 * 8));
+  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  if (tpb > mtiles) tpb = mtiles;
+  dim3 grid((mtiles + tpb - 1) / tpb, ntiles, p.B);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, p, tpb);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
 }
 

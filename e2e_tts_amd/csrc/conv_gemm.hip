@@ -93,43 +93,56 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   float4 breg[BROWS];
   float4 areg[AROWS];
 
+  // Staging loads are UNCONDITIONAL (addresses clamped into the tensor) and the zero fill is applied when the
+  // registers are written to LDS: a load under a runtime predicate makes hipcc branch around it and serialise.
+  const float* wrow[BROWS];
+  bool wok[BROWS];
+#pragma unroll
+  for (int i = 0; i < BROWS; ++i) {
+    const int n = n0 + lrow + i * 32;
+    wok[i] = n < p.Cout;
+    wrow[i] = p.w + (long long)min(n, p.Cout - 1) * KC;
+  }
+  const int cmax = p.Cin - 4;  // Cin % 4 == 0: last float4 of a row
+  bool b_cok = true, a_cok = true;
+  int a_tbase = 0;
+
   auto load_b = [&](int chunk, int j) {
     const int c = chunk * BK + lc4;
+    b_cok = c < p.Cin;
+    const int off = j * p.Cin + min(c, cmax);
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) {
-      const int n = n0 + lrow + i * 32;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < p.Cout && c < p.Cin) v = *reinterpret_cast<const float4*>(p.w + (long long)n * KC + j * p.Cin + c);
-      breg[i] = v;
-    }
+    for (int i = 0; i < BROWS; ++i) breg[i] = *reinterpret_cast<const float4*>(wrow[i] + off);
   };
   auto store_b = [&](int buf) {
     float* dst = Bs + buf * (BN * LDK);
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(dst + (lrow + i * 32) * LDK + lc4) = breg[i];
+    for (int i = 0; i < BROWS; ++i) {
+      float4 v = breg[i];
+      if (!(wok[i] && b_cok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(dst + (lrow + i * 32) * LDK + lc4) = v;
+    }
   };
   auto load_a = [&](int tile, int chunk) {
     const int c = chunk * BK + lc4;
-    const bool cok = c < p.Cin;
-    const int tbase = tile * BM - p.pad;
+    a_cok = c < p.Cin;
+    a_tbase = tile * BM - p.pad;
+    const float* src = in_b + min(c, cmax);
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int r = lrow + i * 32;
-      const int t = tbase + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < arows && cok && t >= 0 && t < p.T) v = *reinterpret_cast<const float4*>(in_b + (long long)t * p.in_ld + c);
-      areg[i] = v;
+      const int t = min(max(a_tbase + lrow + i * 32, 0), p.T - 1);
+      areg[i] = *reinterpret_cast<const float4*>(src + (long long)t * p.in_ld);
     }
   };
   auto store_a = [&]() {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int r = lrow + i * 32;
-      if (r < arows) {
-        float4 v = areg[i];
-        if (p.in_slope != 1.0f) v = lrelu4(v, p.in_slope);
-        *reinterpret_cast<float4*>(As + r * LDK + lc4) = v;
-      }
+      const int t = a_tbase + r;
+      float4 v = areg[i];
+      if (!(a_cok && t >= 0 && t < p.T)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.in_slope != 1.0f) v = lrelu4(v, p.in_slope);
+      if (r < arows) *reinterpret_cast<float4*>(As + r * LDK + lc4) = v;
     }
   };
 
@@ -227,18 +240,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   load_b(0, 0);
   store_b(0);
   int cur = 0;
-  int item = 0, j = 0;  // it = item * KW + j
+  int tl = 0, chunk = 0, j = 0;  // work item = (tile0 + tl, chunk); tap j
   for (int it = 0; it < niter; ++it) {
-    const int tl = item / nchunk, chunk = item - tl * nchunk;
     const bool last_tap = j == p.KW - 1;
-    const bool more_items = item + 1 < nitem;
-    if (last_tap && more_items) {  // next slab: next chunk of this tile, or chunk 0 of the next tile
-      const int nchk = chunk + 1 == nchunk ? 0 : chunk + 1;
-      load_a(tile0 + tl + (nchk == 0 ? 1 : 0), nchk);
-    }
+    const bool tile_done = last_tap && chunk == nchunk - 1;
+    const bool more_items = !(tile_done && tl == ntile - 1);
+    const int nchk = chunk + 1 == nchunk ? 0 : chunk + 1;
+    if (last_tap && more_items) load_a(tile0 + tl + (nchk == 0 ? 1 : 0), nchk);  // next slab: next chunk, or next tile
     if (it + 1 < niter) {  // next weight tile: next tap, or tap 0 of the next item's chunk
       if (!last_tap) load_b(chunk, j + 1);
-      else load_b(chunk + 1 == nchunk ? 0 : chunk + 1, 0);
+      else load_b(nchk, 0);
     }
     __syncthreads();  // slab + Bs[cur] visible
 
@@ -264,15 +275,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
     if (it + 1 < niter) store_b(cur ^ 1);  // that buffer was last read before this iteration's barrier
     cur ^= 1;
     if (last_tap) {
-      const bool tile_done = chunk == nchunk - 1;
       if (tile_done || more_items) __syncthreads();  // every wave is done reading the slab
       if (tile_done) {
         epilogue(tile0 + tl);
         if (more_items) __syncthreads();  // patches read back before the slab is overwritten
+        ++tl;
       }
       if (more_items) store_a();
       j = 0;
-      ++item;
+      chunk = nchk;
     } else {
       ++j;
     }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "kernels.h"
@@ -51,10 +52,11 @@ struct Shape { const char* name; int B, T, Cin, Cout, KW, dil; bool res, acc; fl
 
 int main(int argc, char** argv) {
   int reps = argc > 1 ? atoi(argv[1]) : 10;
+  const char* filter = argc > 2 ? argv[2] : nullptr;
   hipStream_t s;
   CK(hipStreamCreate(&s));
   // ---- correctness on small awkward shapes
-  {
+  if (!filter) {
     Shape checks[] = {{"chk1", 2, 300, 80, 80, 5, 1, true, false, 0.1f}, {"chk2", 3, 777, 32, 32, 11, 5, true, true, 0.1f},
                       {"chk3", 1, 129, 128, 200, 3, 3, false, false, 1.0f}, {"chk4", 2, 64, 384, 1152, 1, 1, false, false, 1.0f},
                       {"chk5", 2, 1000, 64, 64, 7, 3, true, false, 0.1f}, {"chk6", 1, 50, 12, 20, 9, 1, false, false, 1.0f}};
@@ -119,6 +121,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   double tot_ms = 0, tot_fl = 0;
   for (auto& c : shapes) {
+    if (filter && !strstr(c.name, filter)) continue;
     ConvParams p; p.in = din; p.w = dw; p.bias = db; p.res = c.res ? dres : nullptr; p.out = dout;
     p.B = c.B; p.T = c.T; p.Cin = c.Cin; p.Cout = c.Cout; p.KW = c.KW; p.dil = c.dil; p.pad = c.dil * (c.KW - 1) / 2;
     p.in_ld = c.Cin; p.out_ld = c.Cout; p.res_ld = c.Cout; p.in_bs = (long long)c.T * c.Cin; p.out_bs = (long long)c.T * c.Cout; p.res_bs = p.out_bs;

@@ -166,8 +166,17 @@ def main():
         dom = stats_k[0]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         kernel_ms = sum(s["ms"] for s in stats_k) / args.steps
+        # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r*/pmc_summary.md); null when no summary covers the kernel.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = pmc.get(dom["name"], {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                     "launches_per_step": dom["launches"] / args.steps,
                     "all_conv_gemm_tflops": round(sum(s["flops"] for s in stats_k if s["name"].startswith("conv_gemm")) /

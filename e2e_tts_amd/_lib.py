@@ -61,6 +61,8 @@ def load_library() -> C.CDLL:
     lib.e2etts_fetch_pcm.argtypes = [P, P, SZ]
     lib.e2etts_fetch_wav.restype = I
     lib.e2etts_fetch_wav.argtypes = [P, P, SZ]
+    lib.e2etts_set_precision.restype = I
+    lib.e2etts_set_precision.argtypes = [P, I]
     lib.e2etts_profile_enable.restype = I
     lib.e2etts_profile_enable.argtypes = [P, I]
     lib.e2etts_profile_read.restype = I
@@ -78,7 +80,7 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "e2etts_version", "e2etts_last_error", "e2etts_create", "e2etts_destroy", "e2etts_load_weights", "e2etts_acoustic",
     "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
-    "e2etts_fetch_wav", "e2etts_profile_enable", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
+    "e2etts_fetch_wav", "e2etts_set_precision", "e2etts_profile_enable", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
 ]
 
 
@@ -215,6 +217,11 @@ class Engine:
         w = np.empty((B, T * self.dims.hop_length), np.float32)
         self._check(self.lib.e2etts_fetch_wav(self._h, _addr(w), w.size), "e2etts_fetch_wav")
         return w
+
+    def set_precision(self, vocoder: str = "bf16x3"):
+        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, default) for the vocoder convolutions."""
+        mode = {"fp32": 0, "bf16x3": 1}[vocoder]
+        self._check(self.lib.e2etts_set_precision(self._h, mode), "e2etts_set_precision")
 
     # ---- profiling
     def profile_enable(self, on: bool = True):

@@ -27,6 +27,8 @@
 namespace e2etts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -42,6 +44,20 @@ __device__ __forceinline__ float4 lrelu4(float4 v, float slope) {
   return v;
 }
 
+// Split-precision ("bf16x3") helpers.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significant bits.
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const bf16x2 r = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  hi.x = pack_bf16(v.x, v.y);
+  hi.y = pack_bf16(v.z, v.w);
+  const float hx = __builtin_bit_cast(float, hi.x << 16), hy = __builtin_bit_cast(float, hi.x & 0xffff0000u);
+  const float hz = __builtin_bit_cast(float, hi.y << 16), hw = __builtin_bit_cast(float, hi.y & 0xffff0000u);
+  lo.x = pack_bf16(v.x - hx, v.y - hy);
+  lo.y = pack_bf16(v.z - hz, v.w - hw);
+}
+
 __device__ __forceinline__ float act1(float v, int act, float slope) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   if (act == ACT_TANH) return tanhf(v);
@@ -49,7 +65,13 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
   return v;
 }
 
-template <int BM, int BN, int WM, int WN>
+// X3 = false: operands fp32, v_mfma_f32_32x32x2_f32.
+// X3 = true : split precision.  Each fp32 operand is hi + lo (two bf16); the product keeps hi*hi + hi*lo + lo*hi in
+//             three v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative error ~2^-16 per product instead of
+//             bf16's 2^-8; measured on the vocoder: wav mean-L1 9e-7 vs fp64, against 6e-8 for fp32 and 5e-4 for
+//             plain bf16).  An LDS row holds one 32-channel chunk as [32 bf16 hi | 32 bf16 lo | pad] = the same 144
+//             bytes as the fp32 row; activations are split while staging, weights arrive pre-split from the packer.
+template <int BM, int BN, int WM, int WN, bool X3>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
   constexpr int NWN = BN / WN;
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -77,8 +99,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   const int tile0 = blockIdx.x * tiles_per_block;
   const int ntile = min(tiles_per_block, mtiles - tile0);
   const float* in_b = p.in + (long long)b * p.in_bs;
-  const int KC = p.KW * p.Cin;
   const int nchunk = (p.Cin + BK - 1) / BK;
+  const int KC = X3 ? p.KW * nchunk * BK : p.KW * p.Cin;  // X3 weights: [Cout][KW][nchunk][32 words], chunk-padded
   const int nitem = ntile * nchunk;
   const int niter = nitem * p.KW;
 
@@ -109,8 +131,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 
   auto load_b = [&](int chunk, int j) {
     const int c = chunk * BK + lc4;
-    b_cok = c < p.Cin;
-    const int off = j * p.Cin + min(c, cmax);
+    b_cok = X3 ? true : c < p.Cin;  // the packed X3 rows are zero-padded to whole chunks
+    const int off = X3 ? (j * nchunk + chunk) * BK + lc4 : j * p.Cin + min(c, cmax);
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) breg[i] = *reinterpret_cast<const float4*>(wrow[i] + off);
   };
@@ -142,7 +164,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
       float4 v = areg[i];
       if (!(a_cok && t >= 0 && t < p.T)) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.in_slope != 1.0f) v = lrelu4(v, p.in_slope);
-      if (r < arows) *reinterpret_cast<float4*>(As + r * LDK + lc4) = v;
+      if (r < arows) {
+        if constexpr (X3) {
+          uint2 hi, lo;
+          split4(v, hi, lo);
+          *reinterpret_cast<uint2*>(As + r * LDK + (lc4 >> 1)) = hi;        // bf16 channels lc4 .. lc4+3 of the hi half
+          *reinterpret_cast<uint2*>(As + r * LDK + 16 + (lc4 >> 1)) = lo;   // same channels of the lo half
+        } else {
+          *reinterpret_cast<float4*>(As + r * LDK + lc4) = v;
+        }
+      }
     }
   };
 
@@ -255,22 +286,48 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 
     const float* a_base = As + (wm * WM + li + j * p.dil) * LDK + lh * 4;
     const float* b_base = Bs + cur * (BN * LDK) + (wn * WN + li) * LDK + lh * 4;
+    if constexpr (X3) {
+      // lane (row li, half lh) holds k = 16 s + 8 lh .. + 7 of its row: one 16-byte read per operand half
 #pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      float4 af[MT], bf[NT];
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + q * 8);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + q * 8);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+          ah[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + ks * 8));
+          al[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + 16 + ks * 8));
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
+          bh[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + ks * 8));
+          bl[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + 16 + ks * 8));
         }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+        float4 af[MT], bf[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + q * 8);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + q * 8);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
+          }
+      }
     }
     if (it + 1 < niter) store_b(cur ^ 1);  // that buffer was last read before this iteration's barrier
     cur ^= 1;
@@ -290,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool X3>
 const char* launch_cfg(const ConvParams& p, hipStream_t s) {
   const int halo = p.dil * (p.KW - 1);
   const size_t lds = (size_t)((BM + halo) * LDK + 2 * BN * LDK) * sizeof(float);
@@ -303,7 +360,7 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
   tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
   if (tpb > mtiles) tpb = mtiles;
   dim3 grid((mtiles + tpb - 1) / tpb, ntiles, p.B);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, s, p, tpb);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, X3>), grid, dim3(256), lds, s, p, tpb);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
 }
 
@@ -326,9 +383,14 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   if (p.in_ld < p.Cin || p.out_ld < p.Cout || (p.res && p.res_ld < p.Cout)) return "conv_gemm: row stride < channels";
   if (p.dil * (p.KW - 1) > MAX_HALO) return "conv_gemm: dilation * (KW - 1) exceeds the slab halo limit";
   if (p.pad < 0 || p.pad > p.dil * (p.KW - 1)) return "conv_gemm: pad out of range";
-  if (p.Cout > 64) return launch_cfg<128, 128, 64, 64>(p, s);
-  if (p.Cout > 32) return launch_cfg<256, 64, 64, 64>(p, s);
-  return launch_cfg<256, 32, 64, 32>(p, s);
+  if (p.x3) {
+    if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, true>(p, s);
+    if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, true>(p, s);
+    return launch_cfg<256, 32, 64, 32, true>(p, s);
+  }
+  if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, false>(p, s);
+  if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, false>(p, s);
+  return launch_cfg<256, 32, 64, 32, false>(p, s);
 }
 
 }  // namespace e2etts

@@ -54,6 +54,7 @@ struct Predictor {
 };
 struct ConvW {
   const float *w = nullptr, *b = nullptr;
+  const float* wx3 = nullptr;  // split-precision (bf16 hi | lo) image, when the blob carries one
 };
 
 struct ProfRec {
@@ -93,6 +94,7 @@ struct e2etts_engine {
   int64_t* h_mel = nullptr;  // pinned
   int last_B = 0, last_L = 0, last_T = 0, voc_B = 0, voc_T = 0;
   bool have_acoustic = false, have_wav = false;
+  int voc_precision = 1;  // 0: fp32 MFMA, 1: bf16x3 split-precision MFMA (E2ETTS_PRECISION_*)
 
   // profiling
   bool prof_on = false;
@@ -212,7 +214,10 @@ int prof_collect(e2etts_engine* e) {
     if (_m) return (e)->fail(E2ETTS_EINVAL, "%s", _m);             \
   } while (0)
 
-const char* conv_cfg_name(int Cout) { return Cout > 64 ? "conv_gemm_128x128" : (Cout > 32 ? "conv_gemm_256x64" : "conv_gemm_256x32"); }
+const char* conv_cfg_name(int Cout, int x3) {
+  if (x3) return Cout > 64 ? "conv_x3_128x128" : (Cout > 32 ? "conv_x3_256x64" : "conv_x3_256x32");
+  return Cout > 64 ? "conv_gemm_128x128" : (Cout > 32 ? "conv_gemm_256x64" : "conv_gemm_256x32");
+}
 
 // One conv / linear launch.  alg_scale < 1 when part of the packed weight is structural zeros
 // (the polyphase upsampler) so that the recorded FLOPs stay the algorithmic ones.
@@ -223,7 +228,7 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
   if (p.in_bs == 0) p.in_bs = (long long)p.T * p.in_ld;
   if (p.out_bs == 0) p.out_bs = (long long)p.T * p.out_ld;
   if (p.res && p.res_bs == 0) p.res_bs = (long long)p.T * p.res_ld;
-  ProfScope ps(e, conv_cfg_name(p.Cout), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
+  ProfScope ps(e, conv_cfg_name(p.Cout, p.x3), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
   KCHK(e, launch_conv_gemm(p, e->stream));
   return E2ETTS_OK;
 }
@@ -316,20 +321,26 @@ int bind_acoustic(e2etts_engine* e) {
   return E2ETTS_OK;
 }
 
+// fp32 weight + bias (required) and the split-precision image (optional: older blobs do not carry it)
+int bind_conv(e2etts_engine* e, const std::string& name, uint64_t cout, uint64_t kw, uint64_t cin, ConvW& w) {
+  RET(get_tensor(e, name + ".w", cout * kw * cin, &w.w));
+  RET(get_tensor(e, name + ".b", cout, &w.b));
+  w.wx3 = nullptr;
+  if (e->tensors.count(name + ".wx3")) RET(get_tensor(e, name + ".wx3", cout * kw * ((cin + 31) / 32) * 32, &w.wx3));
+  return E2ETTS_OK;
+}
+
 int bind_vocoder(e2etts_engine* e) {
   const auto& c = e->cfg;
   const uint64_t C0 = c.voc_init_ch;
-  RET(get_tensor(e, "voc.pre.w", C0 * 7 * c.n_mel, &e->voc_pre.w));
-  RET(get_tensor(e, "voc.pre.b", C0, &e->voc_pre.b));
+  RET(bind_conv(e, "voc.pre", C0, 7, c.n_mel, e->voc_pre));
   e->voc_up.resize(c.voc_stages);
   e->rb_c1.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
   e->rb_c2.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
   uint64_t ch = C0;
   for (int i = 0; i < c.voc_stages; ++i) {
     const uint64_t cin = ch, cout = ch / 2, s = c.voc_up_rate[i];
-    std::string p = "voc.up." + std::to_string(i) + ".";
-    RET(get_tensor(e, p + "w", s * cout * 3 * cin, &e->voc_up[i].w));
-    RET(get_tensor(e, p + "b", s * cout, &e->voc_up[i].b));
+    RET(bind_conv(e, "voc.up." + std::to_string(i), s * cout, 3, cin, e->voc_up[i]));
     ch = cout;
     for (int j = 0; j < c.voc_n_kernels; ++j) {
       const int idx = i * c.voc_n_kernels + j;
@@ -338,10 +349,8 @@ int bind_vocoder(e2etts_engine* e) {
       e->rb_c2[idx].resize(c.voc_n_dil);
       for (int m = 0; m < c.voc_n_dil; ++m) {
         std::string q = "voc.rb." + std::to_string(idx) + ".";
-        RET(get_tensor(e, q + "c1." + std::to_string(m) + ".w", ch * k * ch, &e->rb_c1[idx][m].w));
-        RET(get_tensor(e, q + "c1." + std::to_string(m) + ".b", ch, &e->rb_c1[idx][m].b));
-        RET(get_tensor(e, q + "c2." + std::to_string(m) + ".w", ch * k * ch, &e->rb_c2[idx][m].w));
-        RET(get_tensor(e, q + "c2." + std::to_string(m) + ".b", ch, &e->rb_c2[idx][m].b));
+        RET(bind_conv(e, q + "c1." + std::to_string(m), ch, k, ch, e->rb_c1[idx][m]));
+        RET(bind_conv(e, q + "c2." + std::to_string(m), ch, k, ch, e->rb_c2[idx][m]));
       }
     }
   }
@@ -631,8 +640,14 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   e->have_wav = false;
   float *S = ptr<float>(e->v0), *XU = ptr<float>(e->v1), *T1 = ptr<float>(e->v2), *CUR = ptr<float>(e->v3);
 
+  // weight selection: split-precision image when requested and present, else fp32
+  auto setw = [&](ConvParams& q, const ConvW& w) {
+    q.bias = w.b;
+    if (e->voc_precision == 1 && w.wx3) { q.w = w.wx3; q.x3 = 1; }
+    else { q.w = w.w; q.x3 = 0; }
+  };
   ConvParams p;
-  p.B = B; p.T = T; p.in = mel_btc; p.w = e->voc_pre.w; p.bias = e->voc_pre.b; p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
+  p.B = B; p.T = T; p.in = mel_btc; setw(p, e->voc_pre); p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
   p.KW = 7; p.pad = 3;
   RET(conv(e, p));
   long long n = T;
@@ -643,7 +658,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     // leaky_relu(0.1) -> ConvTranspose1d(k = 2s, stride s, pad s/2)  (V/generator.py:40-41) as a 3-tap convolution
     // with s * co output channels: row q of the [n, s*co] result IS rows q*s .. q*s+s-1 of the [n*s, co] signal.
     p = ConvParams();
-    p.B = B; p.T = (int)n; p.in = S; p.w = e->voc_up[i].w; p.bias = e->voc_up[i].b; p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
+    p.B = B; p.T = (int)n; p.in = S; setw(p, e->voc_up[i]); p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
     p.KW = 3; p.pad = 1; p.in_slope = 0.1f;
     RET(conv(e, p, 2.0 / 3.0));
     n *= s;
@@ -657,14 +672,14 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         const int d = c.voc_rb_dil[j][m];
         // xt = c1(lrelu(x)); the lrelu that feeds c2 is applied here, in c1's epilogue (V/layers.py:35-38)
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.in = cur; p.w = e->rb_c1[idx][m].w; p.bias = e->rb_c1[idx][m].b; p.out = T1; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.in = cur; setw(p, e->rb_c1[idx][m]); p.out = T1; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = d; p.pad = (k * d - d) / 2; p.in_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f;
         RET(conv(e, p));
         // x = c2(xt) + x (:38-39); the last pair adds into the stage sum, and the last ResBlock divides by num_kernels
         // (V/generator.py:44-48)
         const bool last = m == c.voc_n_dil - 1;
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.in = T1; p.w = e->rb_c2[idx][m].w; p.bias = e->rb_c2[idx][m].b; p.res = cur; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.in = T1; setw(p, e->rb_c2[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = 1; p.pad = (k - 1) / 2;
         if (last) {
           p.out = S;
@@ -692,7 +707,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
 
 extern "C" {
 
-const char* e2etts_version(void) { return "e2etts-hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* e2etts_version(void) { return "e2etts-hip 0.2 (gfx950; fp32 MFMA + bf16x3 split-precision MFMA)"; }
 
 const char* e2etts_last_error(const e2etts_engine* engine) { return engine ? engine->err.c_str() : g_create_error.c_str(); }
 
@@ -917,6 +932,15 @@ int e2etts_fetch_wav(e2etts_engine* e, float* wav_out, size_t capacity) {
   if (capacity < ns) return e->fail(E2ETTS_EINVAL, "buffer holds %zu samples, result has %zu", capacity, ns);
   RET(copy_out(e, wav_out, e->wav.p, ns * 4));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+int e2etts_set_precision(e2etts_engine* e, int vocoder_precision) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (vocoder_precision != E2ETTS_PRECISION_FP32 && vocoder_precision != E2ETTS_PRECISION_BF16X3)
+    return e->fail(E2ETTS_EINVAL, "unknown precision %d", vocoder_precision);
+  e->voc_precision = vocoder_precision;
   return E2ETTS_OK;
 }
 

@@ -75,6 +75,26 @@ def conv_rows(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(w.transpose(0, 2, 1)).reshape(w.shape[0], -1)
 
 
+def pack_x3(w2: np.ndarray, KW: int, Cin: int) -> np.ndarray:
+    """fp32 tap-major conv weight [Cout, KW*Cin] -> split-precision image for the bf16x3 MFMA path:
+    [Cout, KW, ceil(Cin/32), 32 bf16 hi | 32 bf16 lo] with hi = bf16(w), lo = bf16(w - hi) (round to nearest even),
+    returned as 32-bit words [Cout, KW * nchunk * 32] (one LDS row of the kernel = one 32-channel chunk)."""
+    cout = w2.shape[0]
+    nchunk = (Cin + 31) // 32
+    w = np.zeros((cout, KW, nchunk * 32), dtype=np.float32)
+    w[:, :, :Cin] = w2.reshape(cout, KW, Cin)
+
+    def bf16_bits(x):
+        u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+        return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+    hi = bf16_bits(w)
+    hi_f = (hi.astype(np.uint32) << np.uint32(16)).view(np.float32)
+    lo = bf16_bits(w - hi_f)
+    out = np.concatenate([hi.reshape(cout, KW, nchunk, 32), lo.reshape(cout, KW, nchunk, 32)], axis=-1)
+    return np.ascontiguousarray(out).reshape(cout, -1).view(np.float32)
+
+
 def polyphase_upsampler(w: np.ndarray, b: np.ndarray, stride: int):
     """ConvTranspose1d weight [Cin, Cout, K = 2s] (pad s/2) -> 3-tap conv weight [s*Cout, 3*Cin], bias [s*Cout].
 
@@ -181,18 +201,23 @@ def _pack_vocoder(dims: EngineDims, V, out) -> None:
             return fold_weight_norm(need(V, prefix + ".weight_g"), need(V, prefix + ".weight_v")), need(V, prefix + ".bias")
         return need(V, prefix + ".weight"), need(V, prefix + ".bias")  # remove_weight_norm()'d checkpoint
 
+    def put(name, w2, b, KW, cin):
+        out[name + ".w"], out[name + ".b"] = w2, b
+        out[name + ".wx3"] = pack_x3(w2, KW, cin)   # split-precision copy for the bf16x3 path
+
     w, b = voc_weight("conv_pre")
-    out["voc.pre.w"], out["voc.pre.b"] = conv_rows(w), b
+    put("voc.pre", conv_rows(w), b, w.shape[2], w.shape[1])
     nk = len(dims.voc_rb_kernel)
     for i, s in enumerate(dims.voc_up_rate):
         w, b = voc_weight(f"ups.{i}")
-        out[f"voc.up.{i}.w"], out[f"voc.up.{i}.b"] = polyphase_upsampler(w, b, s)
+        w3, b3 = polyphase_upsampler(w, b, s)
+        put(f"voc.up.{i}", w3, b3, 3, w.shape[0])
         for j in range(nk):
             idx = i * nk + j
             for m in range(len(dims.voc_rb_dil[j])):
                 for cs, short in (("convs1", "c1"), ("convs2", "c2")):
                     w, b = voc_weight(f"resblocks.{idx}.{cs}.{m}")
-                    out[f"voc.rb.{idx}.{short}.{m}.w"], out[f"voc.rb.{idx}.{short}.{m}.b"] = conv_rows(w), b
+                    put(f"voc.rb.{idx}.{short}.{m}", conv_rows(w), b, w.shape[2], w.shape[1])
     w, b = voc_weight("conv_post")
     out["voc.post.w"], out["voc.post.b"] = conv_rows(w), b
 

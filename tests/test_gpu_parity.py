@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 MEL_L1 = 1e-4
 WAV_L1 = 1e-4
+PRECISIONS = ("fp32", "bf16x3")  # vocoder arithmetic: both must meet the same bars
 
 _ENGINES = {}
 
@@ -63,15 +64,18 @@ def test_tiny_model_full_trace(name):
     assert mel.shape == g["mel"].shape
     assert mean_l1(mel, g["mel"]) < MEL_L1 / 10
     assert mean_l1(mel_post, g["mel_post"]) < MEL_L1 / 10
-    # vocoder on the engine's own resident mel_post (the production flow) and on the reference's mel
-    wav, pcm = eng.vocoder(None, r["B"], r["T"], wav=True, pcm=True)
-    assert wav.shape == g["wav"].shape
-    assert mean_l1(wav, g["wav"]) < WAV_L1 / 10
-    wav2, _ = eng.vocoder(np.ascontiguousarray(g["mel_post"].transpose(0, 2, 1)), r["B"], r["T"])
-    assert mean_l1(wav2, g["wav"]) < WAV_L1 / 10
-    ref_pcm = (g["wav"] * 32768.0).astype(np.int16)
-    close = np.abs(pcm.astype(np.int32) - ref_pcm.astype(np.int32)) <= 1
-    assert close.mean() >= 0.999
+    # vocoder on the engine's own resident mel_post (the production flow) and on the reference's mel,
+    # in both arithmetic modes (exact fp32 MFMA, and the default split-precision bf16x3 MFMA)
+    for prec in PRECISIONS:
+        eng.set_precision(prec)
+        wav, pcm = eng.vocoder(None, r["B"], r["T"], wav=True, pcm=True)
+        assert wav.shape == g["wav"].shape
+        assert mean_l1(wav, g["wav"]) < WAV_L1 / 10, prec
+        wav2, _ = eng.vocoder(np.ascontiguousarray(g["mel_post"].transpose(0, 2, 1)), r["B"], r["T"])
+        assert mean_l1(wav2, g["wav"]) < WAV_L1 / 10, prec
+        ref_pcm = (g["wav"] * 32768.0).astype(np.int16)
+        close = np.abs(pcm.astype(np.int32) - ref_pcm.astype(np.int32)) <= 1
+        assert close.mean() >= 0.999, prec
 
 
 @pytest.mark.parametrize("name", ["c1_plumbing", "full_b3", "c2_latency"])
@@ -82,13 +86,17 @@ def test_default_model(name):
     check_discrete(r, g)
     assert mean_l1(mel, g["mel"]) < MEL_L1
     assert mean_l1(mel_post, g["mel_post"]) < MEL_L1
-    wav, _ = eng.vocoder(None, r["B"], r["T"])
     s = int(g["wav_stride"])
-    assert mean_l1(wav[:, ::s], g["wav_strided"]) < WAV_L1
-    assert mean_l1(wav[:, :2048], g["wav_head"]) < WAV_L1
     hop = cfg["audio"]["stft"]["hop_length"]
-    for b, n in enumerate(g["mel_lens"] * hop):
-        assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < WAV_L1 * n
+    for prec in PRECISIONS:
+        eng.set_precision(prec)
+        wav, _ = eng.vocoder(None, r["B"], r["T"])
+        err = mean_l1(wav[:, ::s], g["wav_strided"])
+        print(f"{name} {prec}: wav mean-L1 {err:.3e}")
+        assert err < WAV_L1, prec
+        assert mean_l1(wav[:, :2048], g["wav_head"]) < WAV_L1, prec
+        for b, n in enumerate(g["mel_lens"] * hop):
+            assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < WAV_L1 * n, prec
 
 
 def test_c3_mixed_batch32():
@@ -102,12 +110,16 @@ def test_c3_mixed_batch32():
     assert mean_l1(mel_post[sel][:, ::fs], g["mel_post_sel"]) < MEL_L1
     for b, n in enumerate(g["mel_lens"]):
         assert abs(np.abs(mel_post[b, :n].astype(np.float64)).sum() - g["mel_post_abs_sum"][b]) < MEL_L1 * n * 80
-    wav, _ = eng.vocoder(None, r["B"], r["T"])
     ws = int(g["wav_stride"])
-    assert mean_l1(wav[sel][:, ::ws], g["wav_strided_sel"]) < WAV_L1
     hop = cfg["audio"]["stft"]["hop_length"]
-    for b, n in enumerate(g["mel_lens"] * hop):
-        assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < WAV_L1 * n
+    for prec in PRECISIONS:
+        eng.set_precision(prec)
+        wav, _ = eng.vocoder(None, r["B"], r["T"])
+        err = mean_l1(wav[sel][:, ::ws], g["wav_strided_sel"])
+        print(f"c3_mixed {prec}: wav mean-L1 {err:.3e}")
+        assert err < WAV_L1, prec
+        for b, n in enumerate(g["mel_lens"] * hop):
+            assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < WAV_L1 * n, prec
 
 
 def test_vocoder_stage_fixture():
@@ -118,10 +130,14 @@ def test_vocoder_stage_fixture():
     eng = engine_from_states(cfg, cfgmod.DEFAULT_STATS, sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, mode="varied"),
                              sw.make_vocoder_state(cfg, seed=4321))
     B, _, T = g["mel"].shape
-    wav, _ = eng.vocoder(g["mel"], B, T)
-    assert mean_l1(wav, g["wav"][:, 0]) < 1e-6
-    wav2, _ = eng.vocoder(np.ascontiguousarray(g["mel"].transpose(0, 2, 1)), B, T, channels_first=False)
-    np.testing.assert_array_equal(wav, wav2)
+    for prec, bar in (("fp32", 1e-6), ("bf16x3", 1e-5)):
+        eng.set_precision(prec)
+        wav, _ = eng.vocoder(g["mel"], B, T)
+        assert mean_l1(wav, g["wav"][:, 0]) < bar, prec
+        wav2, _ = eng.vocoder(np.ascontiguousarray(g["mel"].transpose(0, 2, 1)), B, T, channels_first=False)
+        np.testing.assert_array_equal(wav, wav2)
+    with pytest.raises(KeyError):
+        eng.set_precision("fp8")
 
 
 def test_oracle_agrees_on_fresh_inputs():

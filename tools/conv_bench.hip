@@ -43,6 +43,25 @@ __global__ void naive_conv(ConvParams p) {
   *o = v;
 }
 
+static unsigned short f2bf(float f) {
+  unsigned u; memcpy(&u, &f, 4);
+  u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16;
+  return (unsigned short)u;
+}
+static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+// fp32 [Cout][KW*Cin] -> x3 layout [Cout][KW][nchunk][32 bf16 hi | 32 bf16 lo] (as 32-bit words)
+static std::vector<float> pack_x3(const std::vector<float>& w, int Cout, int KW, int Cin) {
+  int nchunk = (Cin + 31) / 32;
+  std::vector<unsigned short> out((size_t)Cout * KW * nchunk * 64, 0);
+  for (int n = 0; n < Cout; ++n) for (int j = 0; j < KW; ++j) for (int c = 0; c < Cin; ++c) {
+    float v = w[((size_t)n * KW + j) * Cin + c];
+    unsigned short hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+    size_t base = (((size_t)n * KW + j) * nchunk + c / 32) * 64;
+    out[base + (c % 32)] = hi; out[base + 32 + (c % 32)] = lo;
+  }
+  std::vector<float> r(out.size() / 2); memcpy(r.data(), out.data(), out.size() * 2); return r;
+}
+
 static void fill(std::vector<float>& v, unsigned seed) {
   unsigned s = seed * 2654435761u + 12345u;
   for (auto& x : v) { s = s * 1664525u + 1013904223u; x = ((s >> 8) & 0xffff) / 32768.0f - 1.0f; }
@@ -52,11 +71,12 @@ struct Shape { const char* name; int B, T, Cin, Cout, KW, dil; bool res, acc; fl
 
 int main(int argc, char** argv) {
   int reps = argc > 1 ? atoi(argv[1]) : 10;
-  const char* filter = argc > 2 ? argv[2] : nullptr;
+  const char* filter = argc > 2 && strcmp(argv[2], "-") ? argv[2] : nullptr;
+  const int x3 = argc > 3 && !strcmp(argv[3], "x3");
   hipStream_t s;
   CK(hipStreamCreate(&s));
   // ---- correctness on small awkward shapes
-  if (!filter) {
+  if (!filter || x3) {
     Shape checks[] = {{"chk1", 2, 300, 80, 80, 5, 1, true, false, 0.1f}, {"chk2", 3, 777, 32, 32, 11, 5, true, true, 0.1f},
                       {"chk3", 1, 129, 128, 200, 3, 3, false, false, 1.0f}, {"chk4", 2, 64, 384, 1152, 1, 1, false, false, 1.0f},
                       {"chk5", 2, 1000, 64, 64, 7, 3, true, false, 0.1f}, {"chk6", 1, 50, 12, 20, 9, 1, false, false, 1.0f}};
@@ -69,6 +89,8 @@ int main(int argc, char** argv) {
       CK(hipMalloc(&din, nin * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&db, c.Cout * 4)); CK(hipMalloc(&dres, nout * 4));
       CK(hipMalloc(&dout, nout * 4)); CK(hipMalloc(&dref, nout * 4)); CK(hipMalloc(&dlens, c.B * 4));
       std::vector<int> lens(c.B); for (int b = 0; b < c.B; ++b) lens[b] = c.T - 7 * b;
+      float* dwx = nullptr;
+      if (x3) { auto px = pack_x3(hw, c.Cout, c.KW, c.Cin); CK(hipMalloc(&dwx, px.size() * 4)); CK(hipMemcpy(dwx, px.data(), px.size() * 4, hipMemcpyHostToDevice)); }
       CK(hipMemcpy(din, hin.data(), nin * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(db, hb.data(), c.Cout * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dres, hres.data(), nout * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(dout, hout0.data(), nout * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dref, hout0.data(), nout * 4, hipMemcpyHostToDevice));
@@ -77,16 +99,17 @@ int main(int argc, char** argv) {
       p.B = c.B; p.T = c.T; p.Cin = c.Cin; p.Cout = c.Cout; p.KW = c.KW; p.dil = c.dil; p.pad = c.dil * (c.KW - 1) / 2;
       p.in_ld = c.Cin; p.out_ld = c.Cout; p.res_ld = c.Cout; p.in_bs = (long long)c.T * c.Cin; p.out_bs = (long long)c.T * c.Cout; p.res_bs = p.out_bs;
       p.in_slope = c.slope; p.act = ACT_LRELU; p.act_slope = 0.1f; p.accumulate = c.acc; p.out_div = c.acc ? 3.f : 1.f;
+      ConvParams q = p; q.out = dref;
+      if (x3) { p.w = dwx; p.x3 = 1; }
       const char* m = launch_conv_gemm(p, s);
       if (m) { printf("%s: %s\n", c.name, m); return 1; }
-      ConvParams q = p; q.out = dref;
       hipLaunchKernelGGL(naive_conv, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, q);
       CK(hipStreamSynchronize(s));
       std::vector<float> a(nout), r(nout);
       CK(hipMemcpy(a.data(), dout, nout * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r.data(), dref, nout * 4, hipMemcpyDeviceToHost));
       double maxd = 0; for (size_t i = 0; i < nout; ++i) maxd = fmax(maxd, fabs((double)a[i] - r[i]));
-      printf("check %-5s Cin=%d Cout=%d KW=%d dil=%d: max |diff| = %.3g %s\n", c.name, c.Cin, c.Cout, c.KW, c.dil, maxd, maxd < 2e-4 ? "ok" : "FAIL");
-      if (!(maxd < 2e-4)) return 1;
+      printf("check %-5s Cin=%d Cout=%d KW=%d dil=%d: max |diff| = %.3g %s\n", c.name, c.Cin, c.Cout, c.KW, c.dil, maxd, maxd < (x3 ? 5e-4 : 2e-4) ? "ok" : "FAIL");
+      if (!(maxd < (x3 ? 5e-4 : 2e-4))) return 1;
       hipFree(din); hipFree(dw); hipFree(db); hipFree(dres); hipFree(dout); hipFree(dref); hipFree(dlens);
     }
   }
@@ -118,6 +141,12 @@ int main(int argc, char** argv) {
     std::vector<float> w((size_t)2048 * 3 * 512 + (1 << 18)); fill(w, 8); for (auto& x : w) x *= 0.03f;
     CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, w.data(), 4096 * 4, hipMemcpyHostToDevice));
   }
+  float* dwx3 = nullptr;
+  {  // any finite bf16 pattern will do for timing: pack a random [2048][3*512] matrix once (covers every shape's footprint)
+    std::vector<float> w((size_t)2048 * 3 * 512); fill(w, 9); for (auto& x : w) x *= 0.03f;
+    auto px = pack_x3(w, 2048, 3, 512);
+    CK(hipMalloc(&dwx3, px.size() * 4 + (1 << 20))); CK(hipMemcpy(dwx3, px.data(), px.size() * 4, hipMemcpyHostToDevice));
+  }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   double tot_ms = 0, tot_fl = 0;
   for (auto& c : shapes) {
@@ -126,6 +155,7 @@ int main(int argc, char** argv) {
     p.B = c.B; p.T = c.T; p.Cin = c.Cin; p.Cout = c.Cout; p.KW = c.KW; p.dil = c.dil; p.pad = c.dil * (c.KW - 1) / 2;
     p.in_ld = c.Cin; p.out_ld = c.Cout; p.res_ld = c.Cout; p.in_bs = (long long)c.T * c.Cin; p.out_bs = (long long)c.T * c.Cout; p.res_bs = p.out_bs;
     p.in_slope = c.slope; p.act = c.res ? ACT_NONE : ACT_LRELU; p.act_slope = 0.1f; p.accumulate = c.acc; p.out_div = 1.f;
+    p.x3 = x3; if (x3) p.w = dwx3;
     for (int i = 0; i < 2; ++i) { const char* m = launch_conv_gemm(p, s); if (m) { printf("%s: %s\n", c.name, m); return 1; } }
     CK(hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) launch_conv_gemm(p, s);

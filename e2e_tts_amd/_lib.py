@@ -62,7 +62,7 @@ def load_library() -> C.CDLL:
     lib.e2etts_fetch_wav.restype = I
     lib.e2etts_fetch_wav.argtypes = [P, P, SZ]
     lib.e2etts_set_precision.restype = I
-    lib.e2etts_set_precision.argtypes = [P, I]
+    lib.e2etts_set_precision.argtypes = [P, I, I]
     lib.e2etts_profile_enable.restype = I
     lib.e2etts_profile_enable.argtypes = [P, I]
     lib.e2etts_profile_read.restype = I
@@ -218,10 +218,12 @@ class Engine:
         self._check(self.lib.e2etts_fetch_wav(self._h, _addr(w), w.size), "e2etts_fetch_wav")
         return w
 
-    def set_precision(self, vocoder: str = "bf16x3"):
-        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, default) for the vocoder convolutions."""
-        mode = {"fp32": 0, "bf16x3": 1}[vocoder]
-        self._check(self.lib.e2etts_set_precision(self._h, mode), "e2etts_set_precision")
+    def set_precision(self, vocoder: str = "bf16x3", decoder: Optional[str] = None):
+        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, the default) for the vocoder and for the
+        decoder + mel_linear + postnet (defaults to the vocoder's choice).  Encoder / variance adaptor: always fp32."""
+        modes = {"fp32": 0, "bf16x3": 1}
+        self._check(self.lib.e2etts_set_precision(self._h, modes[vocoder], modes[decoder if decoder is not None else vocoder]),
+                    "e2etts_set_precision")
 
     # ---- profiling
     def profile_enable(self, on: bool = True):

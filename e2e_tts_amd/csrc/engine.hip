@@ -43,6 +43,7 @@ struct BlobEntry {
 
 struct FFTLayer {
   const float *wqkv, *bqkv, *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+  const float *wqkv_x3 = nullptr, *wo_x3 = nullptr, *w1_x3 = nullptr, *w2_x3 = nullptr;  // optional split-precision images
 };
 struct PredLayer {
   const float *w, *b, *g, *beta;
@@ -95,6 +96,7 @@ struct e2etts_engine {
   int last_B = 0, last_L = 0, last_T = 0, voc_B = 0, voc_T = 0;
   bool have_acoustic = false, have_wav = false;
   int voc_precision = 1;  // 0: fp32 MFMA, 1: bf16x3 split-precision MFMA (E2ETTS_PRECISION_*)
+  int dec_precision = 1;  // same choice for decoder + mel_linear + postnet (encoder / variance adaptor: always fp32)
 
   // profiling
   bool prof_on = false;
@@ -262,6 +264,13 @@ int bind_fft(e2etts_engine* e, const char* side, int layers, std::vector<FFTLaye
     RET(get_tensor(e, p + "b2", H, &f.b2));
     RET(get_tensor(e, p + "ln2.g", H, &f.ln2g));
     RET(get_tensor(e, p + "ln2.b", H, &f.ln2b));
+    const uint64_t Hc = (H + 31) / 32 * 32, Fc = (F + 31) / 32 * 32;
+    if (e->tensors.count(p + "wqkv.x3")) {
+      RET(get_tensor(e, p + "wqkv.x3", 3 * H * Hc, &f.wqkv_x3));
+      RET(get_tensor(e, p + "wo.x3", H * Hc, &f.wo_x3));
+      RET(get_tensor(e, p + "w1.x3", F * c.ffn_k1 * Hc, &f.w1_x3));
+      RET(get_tensor(e, p + "w2.x3", H * Fc, &f.w2_x3));
+    }
   }
   return E2ETTS_OK;
 }
@@ -311,12 +320,16 @@ int bind_acoustic(e2etts_engine* e) {
   RET(get_tensor(e, "energy.bins", (uint64_t)c.n_bins - 1, &e->energy_bins));
   RET(get_tensor(e, "mel.w", (uint64_t)c.n_mel * H, &e->mel_lin.w));
   RET(get_tensor(e, "mel.b", c.n_mel, &e->mel_lin.b));
+  e->mel_lin.wx3 = nullptr;
+  if (e->tensors.count("mel.w.x3")) RET(get_tensor(e, "mel.w.x3", (uint64_t)c.n_mel * ((H + 31) / 32 * 32), &e->mel_lin.wx3));
   e->postnet.resize(c.postnet_layers);
   for (int i = 0; i < c.postnet_layers; ++i) {
     const uint64_t cin = i == 0 ? c.n_mel : c.postnet_dim, cout = i == c.postnet_layers - 1 ? c.n_mel : c.postnet_dim;
     std::string p = "post." + std::to_string(i) + ".";
     RET(get_tensor(e, p + "w", cout * c.postnet_kernel * cin, &e->postnet[i].w));
     RET(get_tensor(e, p + "b", cout, &e->postnet[i].b));
+    e->postnet[i].wx3 = nullptr;
+    if (e->tensors.count(p + "w.x3")) RET(get_tensor(e, p + "w.x3", cout * c.postnet_kernel * ((cin + 31) / 32 * 32), &e->postnet[i].wx3));
   }
   return E2ETTS_OK;
 }
@@ -360,7 +373,7 @@ int bind_vocoder(e2etts_engine* e) {
 }
 
 // 6 x FFTBlock (reference U/blocks/transformer.py:178-189), in place on x ([B, N, H]); lens32: device [B]
-int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N) {
+int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3) {
   const auto& c = e->cfg;
   const int H = c.hidden, F = c.ffn_dim;
   float* qkv = ptr<float>(e->qkv);
@@ -371,7 +384,8 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     ConvParams p;
     p.B = B; p.T = N;
     // q | k | v projections as one GEMM (U/blocks/transformer.py:220-222)
-    p.in = x; p.w = f.wqkv; p.bias = f.bqkv; p.out = qkv; p.Cin = H; p.Cout = 3 * H;
+    const bool sx = x3 && f.wqkv_x3;
+    p.in = x; p.w = sx ? f.wqkv_x3 : f.wqkv; p.x3 = sx; p.bias = f.bqkv; p.out = qkv; p.Cin = H; p.Cout = 3 * H;
     RET(conv(e, p));
     {
       const double fl = 4.0 * B * c.n_head * (double)N * N * (H / c.n_head);
@@ -380,7 +394,7 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     }
     // fc + residual (:238-239), LayerNorm eps 1e-5, masked_fill (:182-183)
     p = ConvParams(); p.B = B; p.T = N;
-    p.in = att; p.w = f.wo; p.bias = f.bo; p.res = x; p.out = tmp; p.Cin = H; p.Cout = H;
+    p.in = att; p.w = sx ? f.wo_x3 : f.wo; p.x3 = sx; p.bias = f.bo; p.res = x; p.out = tmp; p.Cin = H; p.Cout = H;
     RET(conv(e, p));
     {
       ProfScope ps(e, "layernorm", 0, 8.0 * B * N * H);
@@ -388,11 +402,11 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     }
     // conv k9 + ReLU, conv k1 + residual, LayerNorm, masked_fill (:289-297, :185-187)
     p = ConvParams(); p.B = B; p.T = N;
-    p.in = xalt; p.w = f.w1; p.bias = f.b1; p.out = hid; p.Cin = H; p.Cout = F; p.KW = c.ffn_k1; p.pad = (c.ffn_k1 - 1) / 2;
+    p.in = xalt; p.w = sx ? f.w1_x3 : f.w1; p.x3 = sx; p.bias = f.b1; p.out = hid; p.Cin = H; p.Cout = F; p.KW = c.ffn_k1; p.pad = (c.ffn_k1 - 1) / 2;
     p.act = ACT_RELU;
     RET(conv(e, p));
     p = ConvParams(); p.B = B; p.T = N;
-    p.in = hid; p.w = f.w2; p.bias = f.b2; p.res = xalt; p.out = tmp; p.Cin = F; p.Cout = H;
+    p.in = hid; p.w = sx ? f.w2_x3 : f.w2; p.x3 = sx; p.bias = f.b2; p.res = xalt; p.out = tmp; p.Cin = F; p.Cout = H;
     RET(conv(e, p));
     {
       ProfScope ps(e, "layernorm", 0, 8.0 * B * N * H);
@@ -523,7 +537,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_embed(ptr<int64_t>(e->ids), e->emb, pos, x, B, L, H, c.n_symbols + 1, e->stream));
   }
-  RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L));
+  RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L, false));  // encoder: always exact fp32
   HIPCHK(e, hipMemcpyAsync(e->encout.p, x, BL * H * 4, hipMemcpyDeviceToDevice, e->stream));
 
   // Variance adaptor, inference branch (U/layers.py:195-258)
@@ -589,10 +603,15 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_length_regulate(xs, ptr<int32_t>(e->cum), ml, dpos, dx, B, L, (int)T, H, e->stream));
   }
-  RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T));
+  RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1));
   // mel_linear (U/model.py:186)
   ConvParams p;
-  p.B = B; p.T = (int)T; p.in = dx; p.w = e->mel_lin.w; p.bias = e->mel_lin.b; p.out = ptr<float>(e->mel); p.Cin = H; p.Cout = c.n_mel;
+  auto setw = [&](ConvParams& q, const ConvW& w) {
+    q.bias = w.b;
+    if (e->dec_precision == 1 && w.wx3) { q.w = w.wx3; q.x3 = 1; }
+    else { q.w = w.w; q.x3 = 0; }
+  };
+  p.B = B; p.T = (int)T; p.in = dx; setw(p, e->mel_lin); p.out = ptr<float>(e->mel); p.Cin = H; p.Cout = c.n_mel;
   RET(conv(e, p));
   // Postnet (U/layers.py:556-563; BatchNorm folded at pack time) + residual (U/model.py:188); unmasked
   const float* pin = ptr<float>(e->mel);
@@ -601,7 +620,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   for (int i = 0; i < c.postnet_layers; ++i) {
     const bool last = i == c.postnet_layers - 1;
     p = ConvParams();
-    p.B = B; p.T = (int)T; p.in = pin; p.w = e->postnet[i].w; p.bias = e->postnet[i].b; p.Cin = cin;
+    p.B = B; p.T = (int)T; p.in = pin; setw(p, e->postnet[i]); p.Cin = cin;
     p.Cout = last ? c.n_mel : c.postnet_dim; p.KW = c.postnet_kernel; p.pad = (c.postnet_kernel - 1) / 2;
     if (last) { p.out = ptr<float>(e->melpost); p.res = ptr<float>(e->mel); }
     else { p.out = bufs[i & 1]; p.act = ACT_TANH; }
@@ -935,12 +954,13 @@ int e2etts_fetch_wav(e2etts_engine* e, float* wav_out, size_t capacity) {
   return E2ETTS_OK;
 }
 
-int e2etts_set_precision(e2etts_engine* e, int vocoder_precision) {
+int e2etts_set_precision(e2etts_engine* e, int vocoder_precision, int decoder_precision) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
-  if (vocoder_precision != E2ETTS_PRECISION_FP32 && vocoder_precision != E2ETTS_PRECISION_BF16X3)
-    return e->fail(E2ETTS_EINVAL, "unknown precision %d", vocoder_precision);
+  for (int v : {vocoder_precision, decoder_precision})
+    if (v != E2ETTS_PRECISION_FP32 && v != E2ETTS_PRECISION_BF16X3) return e->fail(E2ETTS_EINVAL, "unknown precision %d", v);
   e->voc_precision = vocoder_precision;
+  e->dec_precision = decoder_precision;
   return E2ETTS_OK;
 }
 

@@ -160,6 +160,11 @@ def _pack_acoustic(dims: EngineDims, A, out) -> None:
             out[q + "b2"] = need(A, f"{p}.pos_ffn.w_2.bias", (H,))
             out[q + "ln2.g"] = need(A, f"{p}.pos_ffn.layer_norm.weight", (H,))
             out[q + "ln2.b"] = need(A, f"{p}.pos_ffn.layer_norm.bias", (H,))
+            if short == "dec":  # the decoder may run split-precision (nothing discrete depends on it); the encoder never does
+                out[q + "wqkv.x3"] = pack_x3(out[q + "wqkv"], 1, H)
+                out[q + "wo.x3"] = pack_x3(out[q + "wo"], 1, H)
+                out[q + "w1.x3"] = pack_x3(out[q + "w1"], dims.ffn_k1, H)
+                out[q + "w2.x3"] = pack_x3(out[q + "w2"], dims.ffn_k2, dims.ffn_dim)
     va = "variance_adaptor"
     for name, short, layers, kern, chans, odim in (
             ("duration_predictor", "dur", dims.dur_layers, dims.dur_kernel, dims.dur_chans, 1),
@@ -182,6 +187,7 @@ def _pack_acoustic(dims: EngineDims, A, out) -> None:
     out["energy.bins"] = need(A, f"{va}.energy_bins", (dims.n_bins - 1,))
     out["mel.w"] = need(A, "mel_linear.weight", (dims.n_mel, H))
     out["mel.b"] = need(A, "mel_linear.bias", (dims.n_mel,))
+    out["mel.w.x3"] = pack_x3(out["mel.w"], 1, H)
     for i in range(dims.postnet_layers):
         p = f"postnet.convolutions.{i}"
         w = need(A, f"{p}.0.conv.weight").astype(np.float64)
@@ -191,6 +197,7 @@ def _pack_acoustic(dims: EngineDims, A, out) -> None:
         bf = ((b - need(A, f"{p}.1.running_mean").astype(np.float64)) * scale + need(A, f"{p}.1.bias").astype(np.float64)).astype(np.float32)
         out[f"post.{i}.w"] = conv_rows(wf)
         out[f"post.{i}.b"] = bf
+        out[f"post.{i}.w.x3"] = pack_x3(out[f"post.{i}.w"], wf.shape[2], wf.shape[1])
 
 
 def _pack_vocoder(dims: EngineDims, V, out) -> None:

@@ -121,14 +121,15 @@ int e2etts_synthesize(e2etts_engine* engine, const int64_t* ids, const int64_t* 
 int e2etts_fetch_pcm(e2etts_engine* engine, int16_t* pcm_out, size_t capacity);
 int e2etts_fetch_wav(e2etts_engine* engine, float* wav_out, size_t capacity);
 
-/* Arithmetic of the vocoder's convolutions (the acoustic model is always fp32: its duration / pitch / energy
- * decisions must be bit-exact).  E2ETTS_PRECISION_FP32: v_mfma_f32_32x32x2_f32.  E2ETTS_PRECISION_BF16X3 (default):
+/* Arithmetic of the convolutions / projections of (a) the vocoder and (b) the decoder + mel_linear + postnet.
+ * The encoder and the variance adaptor are always exact fp32: the duration / pitch / energy decisions taken there
+ * must be bit-exact, and nothing downstream of the length regulator is discrete.  E2ETTS_PRECISION_FP32: v_mfma_f32_32x32x2_f32.  E2ETTS_PRECISION_BF16X3 (default):
  * every fp32 operand is split into bf16 hi + lo and the product keeps hi*hi + hi*lo + lo*hi on the bf16 matrix
  * pipe with fp32 accumulation -- ~16 significant bits per operand; measured waveform error vs fp64: mean-L1 9e-7
  * (fp32: 6e-8; plain bf16: 5e-4; parity bar: 1e-4). */
 #define E2ETTS_PRECISION_FP32 0
 #define E2ETTS_PRECISION_BF16X3 1
-int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision);
+int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decoder_precision);
 
 /* Per-kernel-class timing with HIP events on the engine's stream (bench.py roofline leg).
  * enable != 0 starts recording (and clears counters); e2etts_profile_read fills up to `cap` records. */

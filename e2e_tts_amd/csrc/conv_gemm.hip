@@ -30,17 +30,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+#ifdef E2ETTS_DIAG
+__device__ unsigned long long g_conv_diag[8];
+#define DIAG_STAMP(var)                                                                        \
+  do {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  } while (0)
+#define DIAG_ADD(slot, t0v, t1v) dsum[slot] += (t1v) - (t0v)
+#else
+#define DIAG_STAMP(var) do {} while (0)
+#define DIAG_ADD(slot, t0v, t1v) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int BK = 32;   // channels per K chunk
 constexpr int LDK = 36;  // padded LDS row stride (floats)
 constexpr int MAX_HALO = 64;
 
-__device__ __forceinline__ float4 lrelu4(float4 v, float slope) {
-  v.x = v.x >= 0.f ? v.x : v.x * slope;
-  v.y = v.y >= 0.f ? v.y : v.y * slope;
-  v.z = v.z >= 0.f ? v.z : v.z * slope;
-  v.w = v.w >= 0.f ? v.w : v.w * slope;
+__device__ __forceinline__ float4 lrelu4(float4 v, float slope) {  // 0 <= slope <= 1: lrelu(x) = max(x, slope * x)
+  v.x = fmaxf(v.x, v.x * slope);
+  v.y = fmaxf(v.y, v.y * slope);
+  v.z = fmaxf(v.z, v.z * slope);
+  v.w = fmaxf(v.w, v.w * slope);
   return v;
 }
 
@@ -115,54 +129,83 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   float4 breg[BROWS];
   float4 areg[AROWS];
 
-  // Staging loads are UNCONDITIONAL (addresses clamped into the tensor) and the zero fill is applied when the
-  // registers are written to LDS: a load under a runtime predicate makes hipcc branch around it and serialise.
-  const float* wrow[BROWS];
+  // Staging loads.  They are UNCONDITIONAL (a load under a runtime predicate makes hipcc branch around it and
+  // serialise) and the zero fill is applied when the registers are written to LDS.  They are buffer loads with a
+  // loop-invariant per-lane offset and a scalar per-iteration offset: no vector address arithmetic in the loop --
+  // next to a wave that streams MFMAs every extra vector instruction costs about one MFMA slot -- and no address
+  // temporaries for hipcc to guard with vmcnt waits against the loads still in flight.
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((long long)p.Cout * KC * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t in_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((long long)p.T * p.in_ld * 4), 0x00020000);
+  int wvoff[BROWS];
   bool wok[BROWS];
+  bool w_all_ok = true;
 #pragma unroll
   for (int i = 0; i < BROWS; ++i) {
     const int n = n0 + lrow + i * 32;
     wok[i] = n < p.Cout;
-    wrow[i] = p.w + (long long)min(n, p.Cout - 1) * KC;
+    wvoff[i] = (min(n, p.Cout - 1) * KC + lc4) * 4;
   }
+  w_all_ok = n0 + BN <= p.Cout;               // uniform: no row of the weight tile needs zeroing
+  const bool ragged = (p.Cin % BK) != 0;      // uniform: the last chunk is partial (fp32 layout only)
+  int avoff[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) avoff[i] = ((lrow + i * 32) * p.in_ld + lc4) * 4;
   const int cmax = p.Cin - 4;  // Cin % 4 == 0: last float4 of a row
-  bool b_cok = true, a_cok = true;
+  bool b_cok = true, a_cok = true, b_mask = false, a_edge = false;
   int a_tbase = 0;
 
   auto load_b = [&](int chunk, int j) {
     const int c = chunk * BK + lc4;
-    b_cok = X3 ? true : c < p.Cin;  // the packed X3 rows are zero-padded to whole chunks
-    const int off = X3 ? (j * nchunk + chunk) * BK + lc4 : j * p.Cin + min(c, cmax);
+    const bool partial = !X3 && ragged && chunk == nchunk - 1;  // X3 rows are zero-padded to whole chunks by the packer
+    b_cok = !partial || c < p.Cin;
+    b_mask = partial || !w_all_ok;
+    // a partial chunk reads past the row end into the next tap / row (or past the tensor: the buffer returns 0); masked below
+    const int soff = (X3 ? (j * nchunk + chunk) * BK : j * p.Cin + chunk * BK) * 4;
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) breg[i] = *reinterpret_cast<const float4*>(wrow[i] + off);
+    for (int i = 0; i < BROWS; ++i)
+      breg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wvoff[i], soff, 0));
   };
   auto store_b = [&](int buf) {
     float* dst = Bs + buf * (BN * LDK);
+    if (b_mask) {
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) {
-      float4 v = breg[i];
-      if (!(wok[i] && b_cok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(dst + (lrow + i * 32) * LDK + lc4) = v;
+      for (int i = 0; i < BROWS; ++i)
+        if (!(wok[i] && b_cok)) breg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(dst + (lrow + i * 32) * LDK + lc4) = breg[i];
   };
   auto load_a = [&](int tile, int chunk) {
     const int c = chunk * BK + lc4;
     a_cok = c < p.Cin;
     a_tbase = tile * BM - p.pad;
-    const float* src = in_b + min(c, cmax);
+    // interior slab of a full chunk: every row and channel exists -> scalar offset, invariant lane offsets
+    a_edge = a_tbase < 0 || a_tbase + AROWS * 32 > p.T || (ragged && chunk == nchunk - 1);
+    if (!a_edge) {
+      const int soff = (a_tbase * p.in_ld + chunk * BK) * 4;
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      const int t = min(max(a_tbase + lrow + i * 32, 0), p.T - 1);
-      areg[i] = *reinterpret_cast<const float4*>(src + (long long)t * p.in_ld);
+      for (int i = 0; i < AROWS; ++i)
+        areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff[i], soff, 0));
+    } else {
+      const int cc = min(c, cmax);
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int t = min(max(a_tbase + lrow + i * 32, 0), p.T - 1);
+        areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (t * p.in_ld + cc) * 4, 0, 0));
+      }
     }
   };
   auto store_a = [&]() {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int r = lrow + i * 32;
-      const int t = a_tbase + r;
       float4 v = areg[i];
-      if (!(a_cok && t >= 0 && t < p.T)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_edge) {
+        const int t = a_tbase + r;
+        if (!(a_cok && t >= 0 && t < p.T)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (p.in_slope != 1.0f) v = lrelu4(v, p.in_slope);
       if (r < arows) {
         if constexpr (X3) {
@@ -178,64 +221,88 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   };
 
   // Epilogue of one output tile.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+  // Vector form: accumulators are transposed through a wave-private LDS patch so that every global access is a float4,
+  // 256 B contiguous per 16 lanes.  It is written branch-light on purpose: bias is fetched before the main loop, the
+  // residual tile is fetched up front with unconditional (clamped) loads, NONE / ReLU / leaky-ReLU are one
+  // max(v, v * slope), and only the stores are predicated -- straight-line code lets hipcc count its vmcnt waits instead
+  // of draining every load and store one at a time (which cost ~16k cycles per tile).
   const bool vec_ok = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && ((p.out_bs & 3) == 0) && (((uintptr_t)p.out & 15) == 0) &&
                       (!p.res || ((p.res_ld % 4 == 0) && ((p.res_bs & 3) == 0) && (((uintptr_t)p.res & 15) == 0))) &&
                       (!p.bias || (((uintptr_t)p.bias & 15) == 0));
   const int len = p.lens ? p.lens[b] : p.T;
   float* out_b = p.out + (long long)b * p.out_bs;
   const float* res_b = p.res ? p.res + (long long)b * p.res_bs : nullptr;
-  auto epilogue = [&](int tile) {
-    const int t0 = tile * BM;
-    if (vec_ok) {
-      float* patch = As + wave * (16 * ELD);  // wave-private: no workgroup barrier between its write and read
-      constexpr int LPR = WN / 4;             // lanes per row when reading float4
-      constexpr int RPP = 64 / LPR;           // rows per pass
-      const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
-      const int col = n0 + wn * WN + pc4;
-      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias && col < p.Cout) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
+  constexpr int LPR = WN / 4;     // lanes per row when the patch is read back as float4
+  constexpr int RPP = 64 / LPR;   // rows per pass
+  constexpr int PASSES = 16 / RPP;
+  const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+  const int ecol = n0 + wn * WN + pc4;
+  const bool ecol_ok = ecol < p.Cout;
+  const int ecol_c = min(ecol, max(p.Cout - 4, 0));
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec_ok && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + ecol_c);
+  const float eslope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LRELU ? p.act_slope : 1.f);
+
+  auto epilogue_vec = [&](int tile, auto has_res) {
+    constexpr bool RES = decltype(has_res)::value;
+    const int t0 = tile * BM + wm * WM;
+    float* patch = As + wave * (16 * ELD);  // wave-private: no workgroup barrier between its write and read
+    float4 resv[MT * 2][PASSES];
+    if constexpr (RES) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int blk = 0; blk < MT * 2; ++blk)
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          __builtin_amdgcn_sched_barrier(0);  // keep the passes apart: hoisting their loads together costs ~100 VGPRs
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int t = min(t0 + blk * 16 + ps * RPP + prow, p.T - 1);
+          resv[blk][ps] = *reinterpret_cast<const float4*>(res_b + (long long)t * p.res_ld + ecol_c);
+        }
+    }
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-              const int r = hh * 8 + rr;
-              const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;  // 0..15 inside this half
-              patch[row * ELD + n * 32 + li] = acc[m][n][r];
-            }
+      for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-          for (int ps = 0; ps < 16 / RPP; ++ps) {
-            const int row = ps * RPP + prow;
-            const int t = t0 + wm * WM + m * 32 + hh * 16 + row;
-            float4 v = *reinterpret_cast<const float4*>(patch + row * ELD + pc4);
-            if (t < p.T && col < p.Cout) {
-              v.x = act1(v.x + bias4.x, p.act, p.act_slope);
-              v.y = act1(v.y + bias4.y, p.act, p.act_slope);
-              v.z = act1(v.z + bias4.z, p.act, p.act_slope);
-              v.w = act1(v.w + bias4.w, p.act, p.act_slope);
-              if (res_b) {
-                const float4 rv = *reinterpret_cast<const float4*>(res_b + (long long)t * p.res_ld + col);
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-              }
-              if (t >= len) v = make_float4(0.f, 0.f, 0.f, 0.f);
-              float4* o = reinterpret_cast<float4*>(out_b + (long long)t * p.out_ld + col);
-              if (p.accumulate) {
-                const float4 ov = *o;
-                v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
-              }
-              if (p.out_div != 1.0f) {
-                v.x = v.x / p.out_div; v.y = v.y / p.out_div; v.z = v.z / p.out_div; v.w = v.w / p.out_div;
-              }
-              *o = v;
-            }
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = hh * 8 + rr;
+            const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;  // 0..15 inside this half
+            patch[row * ELD + n * 32 + li] = acc[m][n][r];
           }
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int row = ps * RPP + prow;
+          const int t = t0 + m * 32 + hh * 16 + row;
+          float4 v = *reinterpret_cast<const float4*>(patch + row * ELD + pc4);
+          v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+          v.x = fmaxf(v.x, v.x * eslope); v.y = fmaxf(v.y, v.y * eslope);
+          v.z = fmaxf(v.z, v.z * eslope); v.w = fmaxf(v.w, v.w * eslope);
+          if (p.act == ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+          if constexpr (RES) {
+            const float4 rv = resv[m * 2 + hh][ps];
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+          }
+          if (t >= len) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          const bool ok = t < p.T && ecol_ok;
+          float4* o = reinterpret_cast<float4*>(out_b + (long long)min(t, p.T - 1) * p.out_ld + ecol_c);
+          if (p.accumulate) {
+            const float4 ov = *o;
+            v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+          }
+          if (p.out_div != 1.0f) {
+            v.x = v.x / p.out_div; v.y = v.y / p.out_div; v.z = v.z / p.out_div; v.w = v.w / p.out_div;
+          }
+          if (ok) *o = v;
         }
       }
+    }
+  };
+  auto epilogue = [&](int tile) {
+    if (vec_ok) {
+      if (res_b) epilogue_vec(tile, std::true_type{});
+      else epilogue_vec(tile, std::false_type{});
     } else {
+      const int t0 = tile * BM;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int col = n0 + wn * WN + n * 32 + li;
@@ -266,24 +333,36 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
   };
 
+  __builtin_amdgcn_s_setprio(3);
   load_a(tile0, 0);
   store_a();
   load_b(0, 0);
   store_b(0);
   int cur = 0;
   int tl = 0, chunk = 0, j = 0;  // work item = (tile0 + tl, chunk); tap j
+#ifdef E2ETTS_DIAG
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
+#endif
   for (int it = 0; it < niter; ++it) {
+    DIAG_STAMP(ta);
     const bool last_tap = j == p.KW - 1;
     const bool tile_done = last_tap && chunk == nchunk - 1;
     const bool more_items = !(tile_done && tl == ntile - 1);
     const int nchk = chunk + 1 == nchunk ? 0 : chunk + 1;
-    if (last_tap && more_items) load_a(tile0 + tl + (nchk == 0 ? 1 : 0), nchk);  // next slab: next chunk, or next tile
+    // Weight tile first, slab second: hipcc reuses the registers of earlier loads for address arithmetic and then
+    // waits (vmcnt) for whatever is in flight -- with the slab loads issued first that was a full HBM round trip.
     if (it + 1 < niter) {  // next weight tile: next tap, or tap 0 of the next item's chunk
       if (!last_tap) load_b(chunk, j + 1);
       else load_b(nchk, 0);
     }
+    if (last_tap && more_items) load_a(tile0 + tl + (nchk == 0 ? 1 : 0), nchk);  // next slab: next chunk, or next tile
+    DIAG_STAMP(tb); DIAG_ADD(0, ta, tb);
     __syncthreads();  // slab + Bs[cur] visible
+    DIAG_STAMP(ta); DIAG_ADD(1, tb, ta);
 
+    // Between two waves of a SIMD the one streaming MFMAs starves the other's vector issue (measured: ~1 MFMA
+    // slot per VALU / VMEM / LDS instruction).  Staging code therefore runs at raised priority, MFMA blocks at 0.
+    __builtin_amdgcn_s_setprio(0);
     const float* a_base = As + (wm * WM + li + j * p.dil) * LDK + lh * 4;
     const float* b_base = Bs + cur * (BN * LDK) + (wn * WN + li) * LDK + lh * 4;
     if constexpr (X3) {
@@ -329,22 +408,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
           }
       }
     }
+    __builtin_amdgcn_s_setprio(3);
+    DIAG_STAMP(tb); DIAG_ADD(2, ta, tb);
     if (it + 1 < niter) store_b(cur ^ 1);  // that buffer was last read before this iteration's barrier
     cur ^= 1;
+    DIAG_STAMP(ta); DIAG_ADD(3, tb, ta);
     if (last_tap) {
       if (tile_done || more_items) __syncthreads();  // every wave is done reading the slab
+      DIAG_STAMP(tb); DIAG_ADD(4, ta, tb);
       if (tile_done) {
         epilogue(tile0 + tl);
         if (more_items) __syncthreads();  // patches read back before the slab is overwritten
         ++tl;
       }
+      DIAG_STAMP(ta); DIAG_ADD(5, tb, ta);
       if (more_items) store_a();
+      DIAG_STAMP(tb); DIAG_ADD(6, ta, tb);
       j = 0;
       chunk = nchk;
     } else {
       ++j;
     }
   }
+#ifdef E2ETTS_DIAG
+  if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+    for (int i = 0; i < 7; ++i) g_conv_diag[i] = dsum[i];
+    g_conv_diag[7] = niter;
+  }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, bool X3>
@@ -366,6 +457,10 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
 
 }  // namespace
 
+#ifdef E2ETTS_DIAG
+void conv_gemm_read_diag(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_diag), sizeof(g_conv_diag)); }
+#endif
+
 double conv_gemm_flops(const ConvParams& p) { return 2.0 * p.B * (double)p.T * p.Cout * p.KW * p.Cin; }
 
 double conv_gemm_bytes(const ConvParams& p) {
@@ -383,6 +478,9 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   if (p.in_ld < p.Cin || p.out_ld < p.Cout || (p.res && p.res_ld < p.Cout)) return "conv_gemm: row stride < channels";
   if (p.dil * (p.KW - 1) > MAX_HALO) return "conv_gemm: dilation * (KW - 1) exceeds the slab halo limit";
   if (p.pad < 0 || p.pad > p.dil * (p.KW - 1)) return "conv_gemm: pad out of range";
+  if (p.in_slope < 0.f || p.in_slope > 1.f) return "conv_gemm: in_slope must lie in [0, 1]";
+  if ((long long)p.T * p.in_ld * 4 >= (1LL << 31) || (long long)p.Cout * p.KW * ((p.Cin + 31) / 32 * 32) * 4 >= (1LL << 31))
+    return "conv_gemm: one utterance / the weight matrix must stay below 2 GiB (32-bit buffer offsets)";
   if (p.x3) {
     if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, true>(p, s);
     if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, true>(p, s);

@@ -11,6 +11,9 @@
 #include "kernels.h"
 
 using namespace e2etts;
+#ifdef E2ETTS_DIAG
+namespace e2etts { void conv_gemm_read_diag(unsigned long long* out); }
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -162,6 +165,13 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     double fl = conv_gemm_flops(p);
+#ifdef E2ETTS_DIAG
+    { unsigned long long d[8]; conv_gemm_read_diag(d);
+      const char* nm[7] = {"issue loads", "barrier", "frags+mfma", "store_b", "item barrier", "epilogue", "store_a"};
+      printf("   diag (cycles per iteration, %llu iterations):", d[7]);
+      for (int i = 0; i < 7; ++i) printf(" %s=%.0f", nm[i], (double)d[i] / (double)d[7]);
+      printf("\n"); }
+#endif
     printf("%-20s Cin=%4d Cout=%4d KW=%2d dil=%d T=%6d : %8.3f ms  %7.2f TFLOP/s  %7.1f GB/s\n", c.name, c.Cin, c.Cout, c.KW, c.dil, c.T, ms,
            fl / ms / 1e9, conv_gemm_bytes(p) / ms / 1e6);
     tot_ms += ms; tot_fl += fl;

@@ -61,6 +61,12 @@ def load_library() -> C.CDLL:
     lib.e2etts_fetch_pcm.argtypes = [P, P, SZ]
     lib.e2etts_fetch_wav.restype = I
     lib.e2etts_fetch_wav.argtypes = [P, P, SZ]
+    lib.e2etts_vocoder_stream_begin.restype = I
+    lib.e2etts_vocoder_stream_begin.argtypes = [P, I]
+    lib.e2etts_vocoder_stream_push.restype = I
+    lib.e2etts_vocoder_stream_push.argtypes = [P, P, I, I, C.POINTER(I)]
+    lib.e2etts_vocoder_stream_fetch.restype = I
+    lib.e2etts_vocoder_stream_fetch.argtypes = [P, P, P, SZ]
     lib.e2etts_set_precision.restype = I
     lib.e2etts_set_precision.argtypes = [P, I, I]
     lib.e2etts_profile_enable.restype = I
@@ -80,7 +86,8 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "e2etts_version", "e2etts_last_error", "e2etts_create", "e2etts_destroy", "e2etts_load_weights", "e2etts_acoustic",
     "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
-    "e2etts_fetch_wav", "e2etts_set_precision", "e2etts_profile_enable", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
+    "e2etts_fetch_wav", "e2etts_vocoder_stream_begin", "e2etts_vocoder_stream_push", "e2etts_vocoder_stream_fetch",
+    "e2etts_set_precision", "e2etts_profile_enable", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
 ]
 
 
@@ -221,9 +228,32 @@ class Engine:
     def set_precision(self, vocoder: str = "bf16x3", decoder: Optional[str] = None):
         """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, the default) for the vocoder and for the
         decoder + mel_linear + postnet (defaults to the vocoder's choice).  Encoder / variance adaptor: always fp32."""
-        modes = {"fp32": 0, "bf16x3": 1}
-        self._check(self.lib.e2etts_set_precision(self._h, modes[vocoder], modes[decoder if decoder is not None else vocoder]),
-                    "e2etts_set_precision")
+        modes = {"fp32": 0, "bf16x3": 1, "bf16": 2}   # 'bf16' (plain, vocoder only) is the long-form streaming config's arithmetic
+        dec = decoder if decoder is not None else ("bf16x3" if vocoder == "bf16" else vocoder)
+        self._check(self.lib.e2etts_set_precision(self._h, modes[vocoder], modes[dec]), "e2etts_set_precision")
+
+    # ---- long-form / streaming vocoder
+    def vocoder_stream(self, chunks, B: int, want_pcm: bool = False):
+        """Generator: feed an iterable of mel chunks [B, n, n_mel] (numpy / torch, channels-last), yield the waveform (or
+        int16 PCM) pieces [B, n_emit * hop] as they become final.  Concatenated along axis 1 they equal
+        ``vocoder(whole_mel)`` bit for bit, while HBM use stays bounded by the chunk size."""
+        halo = self._check(self.lib.e2etts_vocoder_stream_begin(self._h, B), "e2etts_vocoder_stream_begin")
+        self.stream_halo = halo
+        chunks = iter(chunks)
+        cur = next(chunks, None)
+        while cur is not None:
+            nxt = next(chunks, None)
+            n = int(cur.shape[1])
+            n_emit = C.c_int(0)
+            self._check(self.lib.e2etts_vocoder_stream_push(self._h, _addr(cur), n, 1 if nxt is None else 0, C.byref(n_emit)),
+                        "e2etts_vocoder_stream_push")
+            if n_emit.value > 0:
+                ns = n_emit.value * self.dims.hop_length
+                out = np.empty((B, ns), np.int16 if want_pcm else np.float32)
+                self._check(self.lib.e2etts_vocoder_stream_fetch(self._h, None if want_pcm else _addr(out),
+                                                                 _addr(out) if want_pcm else None, out.size), "e2etts_vocoder_stream_fetch")
+                yield out
+            cur = nxt
 
     # ---- profiling
     def profile_enable(self, on: bool = True):

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   const int tile0 = blockIdx.x * tiles_per_block;
   const int ntile = min(tiles_per_block, mtiles - tile0);
   const float* in_b = p.in + (long long)b * p.in_bs;
+  const bool split = p.x3 != 2;  // uniform
   const int nchunk = (p.Cin + BK - 1) / BK;
   const int KC = X3 ? p.KW * nchunk * BK : p.KW * p.Cin;  // X3 weights: [Cout][KW][nchunk][32 words], chunk-padded
   const int nitem = ntile * nchunk;
@@ -384,8 +385,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+            if (split) {  // the two cross terms; skipped in plain-bf16 mode (x3 == 2)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+            }
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
           }
       }

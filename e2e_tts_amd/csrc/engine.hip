@@ -95,7 +95,12 @@ struct e2etts_engine {
   int64_t* h_mel = nullptr;  // pinned
   int last_B = 0, last_L = 0, last_T = 0, voc_B = 0, voc_T = 0;
   bool have_acoustic = false, have_wav = false;
-  int voc_precision = 1;  // 0: fp32 MFMA, 1: bf16x3 split-precision MFMA (E2ETTS_PRECISION_*)
+  int voc_precision = 1;  // 0: fp32 MFMA, 1: bf16x3 split-precision MFMA, 2: plain bf16 (E2ETTS_PRECISION_*)
+  // streaming vocoder (e2etts_vocoder_stream_*): trailing mel frames kept as context / not yet emitted
+  DevBuf st_carry, st_win;
+  int st_B = 0, st_carry_n = 0, st_halo = 0, st_emit_n = 0, st_emit_off = 0, st_win_n = 0;
+  long long st_emitted = 0;
+  bool st_open = false, st_done = false;
   int dec_precision = 1;  // same choice for decoder + mel_linear + postnet (encoder / variance adaptor: always fp32)
 
   // profiling
@@ -662,7 +667,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   // weight selection: split-precision image when requested and present, else fp32
   auto setw = [&](ConvParams& q, const ConvW& w) {
     q.bias = w.b;
-    if (e->voc_precision == 1 && w.wx3) { q.w = w.wx3; q.x3 = 1; }
+    if (e->voc_precision != E2ETTS_PRECISION_FP32 && w.wx3) { q.w = w.wx3; q.x3 = e->voc_precision; }
     else { q.w = w.w; q.x3 = 0; }
   };
   ConvParams p;
@@ -773,7 +778,7 @@ void e2etts_destroy(e2etts_engine* e) {
   DevBuf* bufs[] = {&e->blob, &e->ids, &e->lens64, &e->lens32, &e->spk, &e->xa, &e->xb, &e->xs, &e->xp, &e->tmp, &e->qkv, &e->att,
                     &e->hid, &e->p1, &e->p2, &e->logd, &e->durf, &e->cum, &e->mel64, &e->mel32, &e->posbuf, &e->ppred, &e->epred,
                     &e->pidx, &e->eidx, &e->dx, &e->dxb, &e->mel, &e->melpost, &e->pn1, &e->pn2, &e->encout, &e->melin, &e->v0,
-                    &e->v1, &e->v2, &e->v3, &e->wav, &e->pcm};
+                    &e->v1, &e->v2, &e->v3, &e->wav, &e->pcm, &e->st_carry, &e->st_win};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
@@ -954,11 +959,105 @@ int e2etts_fetch_wav(e2etts_engine* e, float* wav_out, size_t capacity) {
   return E2ETTS_OK;
 }
 
+// Frames of mel context one output frame depends on, each side (conservative bound from the layer geometry: conv_post 3
+// samples, per stage the widest ResBlock1 sum_m ((k-1)/2 d_m + (k-1)/2), each upsampler +-2 input positions, conv_pre 3 frames).
+static int vocoder_halo_frames(const e2etts_config& c) {
+  double r = 3.0;
+  for (int i = c.voc_stages - 1; i >= 0; --i) {
+    int worst = 0;
+    for (int j = 0; j < c.voc_n_kernels; ++j) {
+      int sum = 0;
+      for (int m = 0; m < c.voc_n_dil; ++m) sum += (c.voc_rb_kernel[j] - 1) / 2 * (c.voc_rb_dil[j][m] + 1);
+      worst = std::max(worst, sum);
+    }
+    r = (r + worst) / c.voc_up_rate[i] + 2.0;
+  }
+  return (int)std::ceil(r + 3.0);
+}
+
+int e2etts_vocoder_stream_begin(e2etts_engine* e, int B) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->voc_loaded) return e->fail(E2ETTS_ESTATE, "vocoder weights not loaded");
+  if (B <= 0 || B > 4096) return e->fail(E2ETTS_EINVAL, "B out of range");
+  e->st_B = B;
+  e->st_carry_n = 0;
+  e->st_emitted = 0;
+  e->st_emit_n = 0;
+  e->st_halo = vocoder_halo_frames(e->cfg);
+  e->st_open = true;
+  e->st_done = false;
+  return e->st_halo;
+}
+
+int e2etts_vocoder_stream_push(e2etts_engine* e, const float* mel_btc, int n, int last, int* n_frames_out) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->st_open || e->st_done) return e->fail(E2ETTS_ESTATE, "no open vocoder stream");
+  if (n < 0 || (n > 0 && !mel_btc)) return e->fail(E2ETTS_EINVAL, "bad chunk");
+  const int B = e->st_B, H = e->st_halo, M = e->cfg.n_mel;
+  const int total = e->st_carry_n + n;
+  if (n_frames_out) *n_frames_out = 0;
+  e->st_emit_n = 0;
+  // window = [carry | new]; carry = up to H already-emitted frames (left context) followed by the frames not yet emitted
+  const int left_ctx = (int)std::min<long long>(H, std::min<long long>(e->st_emitted, e->st_carry_n));
+  const int emit_end = last ? total : total - H;   // frames before emit_end have their full right context in the window
+  RET(ensure(e, e->st_win, (size_t)B * std::max(total, 1) * M * 4));
+  const size_t row_new = (size_t)n * M * 4, row_carry = (size_t)e->st_carry_n * M * 4, row_win = (size_t)total * M * 4;
+  if (e->st_carry_n)
+    HIPCHK(e, hipMemcpy2DAsync(e->st_win.p, row_win, e->st_carry.p, row_carry, row_carry, B, hipMemcpyDeviceToDevice, e->stream));
+  if (n)
+    HIPCHK(e, hipMemcpy2DAsync((char*)e->st_win.p + row_carry, row_win, mel_btc, row_new, row_new, B, hipMemcpyDefault, e->stream));
+  int n_emit = emit_end - left_ctx;
+  if (n_emit > 0) {
+    RET(vocoder_impl(e, ptr<float>(e->st_win), B, total, true, true));
+    e->st_win_n = total;
+    e->st_emit_off = left_ctx;
+    e->st_emit_n = n_emit;
+    e->st_emitted += n_emit;
+  } else {
+    n_emit = 0;
+  }
+  // next carry: H frames of emitted context + everything not yet emitted
+  const int keep_from = std::max(0, (n_emit > 0 ? emit_end : left_ctx) - H);
+  const int keep_n = last ? 0 : total - keep_from;
+  if (keep_n > 0) {
+    RET(ensure(e, e->st_carry, (size_t)B * keep_n * M * 4));
+    HIPCHK(e, hipMemcpy2DAsync(e->st_carry.p, (size_t)keep_n * M * 4, (char*)e->st_win.p + (size_t)keep_from * M * 4, row_win,
+                               (size_t)keep_n * M * 4, B, hipMemcpyDeviceToDevice, e->stream));
+  }
+  e->st_carry_n = keep_n;
+  if (last) e->st_done = true;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (n_frames_out) *n_frames_out = n_emit;
+  return E2ETTS_OK;
+}
+
+int e2etts_vocoder_stream_fetch(e2etts_engine* e, float* wav_out, int16_t* pcm_out, size_t capacity) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->st_open || e->st_emit_n <= 0) return e->fail(E2ETTS_ESTATE, "the last push emitted nothing");
+  const size_t hop = e->cfg.hop_length, ns = (size_t)e->st_emit_n * hop;
+  if (capacity < (size_t)e->st_B * ns) return e->fail(E2ETTS_EINVAL, "buffer holds %zu samples, chunk has %zu", capacity, (size_t)e->st_B * ns);
+  const size_t src_row = (size_t)e->st_win_n * hop, off = (size_t)e->st_emit_off * hop;
+  if (wav_out)
+    HIPCHK(e, hipMemcpy2DAsync(wav_out, ns * 4, ptr<float>(e->wav) + off, src_row * 4, ns * 4, e->st_B, hipMemcpyDefault, e->stream));
+  if (pcm_out)
+    HIPCHK(e, hipMemcpy2DAsync(pcm_out, ns * 2, ptr<int16_t>(e->pcm) + off, src_row * 2, ns * 2, e->st_B, hipMemcpyDefault, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
 int e2etts_set_precision(e2etts_engine* e, int vocoder_precision, int decoder_precision) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
-  for (int v : {vocoder_precision, decoder_precision})
-    if (v != E2ETTS_PRECISION_FP32 && v != E2ETTS_PRECISION_BF16X3) return e->fail(E2ETTS_EINVAL, "unknown precision %d", v);
+  if (vocoder_precision != E2ETTS_PRECISION_FP32 && vocoder_precision != E2ETTS_PRECISION_BF16X3 &&
+      vocoder_precision != E2ETTS_PRECISION_BF16)
+    return e->fail(E2ETTS_EINVAL, "unknown vocoder precision %d", vocoder_precision);
+  if (decoder_precision != E2ETTS_PRECISION_FP32 && decoder_precision != E2ETTS_PRECISION_BF16X3)
+    return e->fail(E2ETTS_EINVAL, "decoder precision must be fp32 or bf16x3 (got %d)", decoder_precision);
   e->voc_precision = vocoder_precision;
   e->dec_precision = decoder_precision;
   return E2ETTS_OK;

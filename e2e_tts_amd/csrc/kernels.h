@@ -15,7 +15,7 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3 };
 struct ConvParams {
   const float* in = nullptr;     // [B, T, Cin]  (row stride in_ld, batch stride in_bs)
   const float* w = nullptr;      // [Cout, KW*Cin] tap-major fp32; x3: [Cout, KW, ceil(Cin/32), 32 bf16 hi | 32 bf16 lo]
-  int x3 = 0;                    // 1: split-precision bf16x3 MFMA path (w pre-split by the packer)
+  int x3 = 0;                    // 1: split-precision bf16x3 MFMA path (w pre-split by the packer); 2: plain bf16 (hi x hi only)
   const float* bias = nullptr;   // [Cout] or null
   const float* res = nullptr;    // optional residual, same indexing as out
   float* out = nullptr;          // [B, T, Cout]

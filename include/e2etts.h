@@ -121,6 +121,17 @@ int e2etts_synthesize(e2etts_engine* engine, const int64_t* ids, const int64_t* 
 int e2etts_fetch_pcm(e2etts_engine* engine, int16_t* pcm_out, size_t capacity);
 int e2etts_fetch_wav(e2etts_engine* engine, float* wav_out, size_t capacity);
 
+/* Long-form / streaming vocoder (BASELINE config 5).  The mel stream of B parallel utterances is pushed in chunks of any
+ * size, channels-last [B, n, n_mel] (host or device memory); the engine keeps the receptive-field halo (returned by
+ * _begin, in frames; 15 for the default HiFi-GAN V1) and the not-yet-emittable tail internally, so HBM use is bounded by
+ * the chunk size, and the concatenated output is bit-identical to one e2etts_vocoder call on the whole mel.
+ *   _begin(B)                      -> halo in frames (>= 0) or a negative error
+ *   _push(mel, n, last, &n_emit)   -> runs the vocoder on [context | pending | new]; n_emit frames became final
+ *   _fetch(wav, pcm, capacity)     -> copies those n_emit * hop samples per utterance, [B, n_emit * hop] compact */
+int e2etts_vocoder_stream_begin(e2etts_engine* engine, int B);
+int e2etts_vocoder_stream_push(e2etts_engine* engine, const float* mel_btc, int n_frames, int last, int* n_frames_out);
+int e2etts_vocoder_stream_fetch(e2etts_engine* engine, float* wav_out, int16_t* pcm_out, size_t capacity);
+
 /* Arithmetic of the convolutions / projections of (a) the vocoder and (b) the decoder + mel_linear + postnet.
  * The encoder and the variance adaptor are always exact fp32: the duration / pitch / energy decisions taken there
  * must be bit-exact, and nothing downstream of the length regulator is discrete.  E2ETTS_PRECISION_FP32: v_mfma_f32_32x32x2_f32.  E2ETTS_PRECISION_BF16X3 (default):
@@ -129,6 +140,8 @@ int e2etts_fetch_wav(e2etts_engine* engine, float* wav_out, size_t capacity);
  * (fp32: 6e-8; plain bf16: 5e-4; parity bar: 1e-4). */
 #define E2ETTS_PRECISION_FP32 0
 #define E2ETTS_PRECISION_BF16X3 1
+#define E2ETTS_PRECISION_BF16 2 /* vocoder only: hi x hi product alone (plain bf16 operands, fp32 accumulation): the arithmetic
+                                   BASELINE config 5 (long-form streaming) names; waveform error ~5e-4, above the fp32 bar */
 int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decoder_precision);
 
 /* Per-kernel-class timing with HIP events on the engine's stream (bench.py roofline leg).

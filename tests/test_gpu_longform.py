@@ -1,0 +1,94 @@
+"""GPU tests (-m gpu) of BASELINE config 5: 48 kHz-style HiFi-GAN (upsample 8x8x4x2 = hop 512), long-form mel stream
+(>= 60 s of audio) through the streaming vocoder in bf16.  The reference ships no 48 kHz config: its
+HifiGan class is config-driven, and so are the oracle and the engine, so the same restatement serves as the oracle."""
+import numpy as np
+import pytest
+
+from e2e_tts_amd import config as cfgmod, synth_weights as sw
+
+pytestmark = pytest.mark.gpu
+
+
+def cfg48(width):
+    cfg = cfgmod.default_config()
+    cfg["models"]["hifigan"].update(upsample_rates=[8, 8, 4, 2], upsample_kernel_sizes=[16, 16, 8, 4], upsample_initial_channel=width)
+    cfg["audio"]["stft"]["hop_length"] = 512
+    cfg["audio"]["signal"]["sampling_rate"] = 48000
+    return cfg
+
+
+def make_engine(cfg, seed):
+    from e2e_tts_amd.models import HifiGan
+    voc = sw.make_vocoder_state(cfg, seed=seed)
+    v = HifiGan(cfg["models"]["hifigan"])
+    v.load_state_dict(sw.to_torch(voc))
+    return voc, v.eval().to(0).engine
+
+
+def mean_l1(a, b):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).mean())
+
+
+def test_48k_vocoder_matches_oracle_in_all_precisions():
+    from oracle import ref_numpy as orc
+    cfg = cfg48(64)
+    voc, eng = make_engine(cfg, 31)
+    assert eng.dims.hop_length == 512
+    rng = np.random.Generator(np.random.PCG64(5))
+    mel = rng.standard_normal((2, 90, 80)).astype(np.float32)
+    ref = orc.VocoderOracle(voc, cfg).forward(mel.transpose(0, 2, 1))[:, 0]
+    assert ref.shape == (2, 90 * 512)
+    errs = {}
+    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 5e-3)):   # stated tolerance for plain bf16: 5e-3 mean-L1
+        eng.set_precision(prec)
+        wav, _ = eng.vocoder(mel, 2, 90, channels_first=False)
+        errs[prec] = mean_l1(wav, ref)
+        assert errs[prec] < bar, (prec, errs[prec])
+    print("48k vocoder mean-L1 vs oracle:", errs)
+    assert errs["fp32"] <= errs["bf16x3"] < errs["bf16"]
+
+
+def test_streaming_equals_one_shot_bit_for_bit():
+    cfg = cfg48(64)
+    _, eng = make_engine(cfg, 32)
+    rng = np.random.Generator(np.random.PCG64(6))
+    T = 333
+    mel = rng.standard_normal((3, T, 80)).astype(np.float32)
+    for prec in ("bf16x3", "bf16"):
+        eng.set_precision(prec)
+        whole, whole_pcm = eng.vocoder(mel, 3, T, channels_first=False, pcm=True)
+        for sizes in ([T], [1, 7, 40, 3, 100, 2, 180], [16] * 20 + [13], [200, 133]):
+            assert sum(sizes) == T
+            pieces, pos = [], 0
+            chunks = []
+            for n in sizes:
+                chunks.append(np.ascontiguousarray(mel[:, pos:pos + n]))
+                pos += n
+            out = np.concatenate(list(eng.vocoder_stream(chunks, 3)), axis=1)
+            assert out.shape == whole.shape
+            np.testing.assert_array_equal(out, whole)
+        pcm = np.concatenate(list(eng.vocoder_stream([np.ascontiguousarray(mel[:, :150]), np.ascontiguousarray(mel[:, 150:])], 3, want_pcm=True)), axis=1)
+        np.testing.assert_array_equal(pcm, whole_pcm)
+    assert 8 <= eng.stream_halo <= 24
+
+
+def test_long_form_60s_stream_bf16():
+    """>= 60 s of 48 kHz audio (5 632 frames x 512) from one utterance, default-width generator, plain bf16, chunks of 512
+    frames; checked against the one-shot run (bit-exact) and against the split-precision run (stated bf16 tolerance)."""
+    cfg = cfg48(512)
+    _, eng = make_engine(cfg, 33)
+    rng = np.random.Generator(np.random.PCG64(7))
+    T = 5632
+    mel = (0.7 * rng.standard_normal((1, T, 80))).astype(np.float32)
+    eng.set_precision("bf16")
+    chunks = [np.ascontiguousarray(mel[:, i:i + 512]) for i in range(0, T, 512)]
+    out = np.concatenate(list(eng.vocoder_stream(chunks, 1)), axis=1)
+    assert out.shape == (1, T * 512) and out.shape[1] / 48000 >= 60.0
+    assert np.isfinite(out).all() and np.abs(out).max() <= 1.0
+    whole, _ = eng.vocoder(mel, 1, T, channels_first=False)
+    np.testing.assert_array_equal(out, whole)
+    eng.set_precision("bf16x3")
+    exact, _ = eng.vocoder(mel, 1, T, channels_first=False)
+    err = mean_l1(out, exact)
+    print(f"long-form bf16 vs bf16x3: mean-L1 {err:.3e}")
+    assert err < 5e-3

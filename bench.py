@@ -192,6 +192,28 @@ def main():
                     "all_conv_gemm_tflops": round(sum(s["flops"] for s in stats_k if s["name"].startswith("conv_gemm")) /
                                                   (sum(s["ms"] for s in stats_k if s["name"].startswith("conv_gemm")) * 1e-3) / 1e12, 3),
                     "kernel_ms_per_step": round(kernel_ms, 3)}
+        # the same hot path with every convolution on the exact-fp32 MFMA (e2etts_set_precision fp32): reported beside the
+        # default split-precision run so that both kernels' roofline fractions are on record
+        fp32_mode = None
+        if args.precision != "fp32":
+            eng.set_precision("fp32")
+            step()
+            eng.profile_enable(True)
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            tf = (time.perf_counter() - tf0) / 3
+            st32 = sorted(eng.profile_read(), key=lambda s: -s["ms"])
+            eng.profile_enable(False)
+            eng.set_precision(args.precision)
+            d32 = st32[0]
+            a32 = d32["flops"] / (d32["ms"] * 1e-3) / 1e12
+            fp32_mode = {"ms_per_step": round(tf * 1e3, 3), "samples_per_s": round(B * T * hop / tf), "kernel": d32["name"],
+                         "achieved": round(a32, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(a32 / PEAK_FP32_TFLOPS, 4),
+                         "avg_launch_us": round(d32["ms"] / d32["launches"] * 1e3, 2)}
+            log(f"[bench] fp32 mode: {fp32_mode}")
         # host-inclusive variant (ids from host memory, PCM back to host memory): reported, never `value`
         ids_h, lens_h, spk_h = ids.cpu().numpy(), lens.cpu().numpy(), spk.cpu().numpy()
         pcm_h = np.empty((B, T * hop), np.int16)
@@ -214,6 +236,7 @@ def main():
             "real_time_factor": value / dims.sample_rate,
             "host_inclusive_samples_per_s_per_gpu": host_rate,
             "roofline": roofline,
+            "fp32_mode": fp32_mode,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, stats, ac_state, voc_state)

@@ -1,0 +1,461 @@
+// conv_pp: the wide-output (Cout > 64) instantiation of the implicit-GEMM convolution as an 8-wavefront
+// PING-PONG workgroup, one per CU.
+//
+// Why: in conv_gemm (4 waves per workgroup, 2 workgroups per CU) the two waves that share a SIMD overlap their MFMA
+// phase and their staging phase only by chance; s_memtime stamps show ~1 350 cycles of staging / barrier / epilogue per
+// 768 MFMA cycles per wave in the split-precision kernel, and the matrix pipe 48 % busy.  Here the overlap is by
+// construction: a 512-thread workgroup is two GROUPS of four waves (waves w and w + 4 share a SIMD); each group owns
+// its own 128-row output tile with its own activation slab, both share the weight tiles, and every (chunk, tap)
+// iteration runs as two phases separated by workgroup barriers:
+//     phase A: group 0 issues its MFMAs      | group 1 stages (publishes its half of the next weight tile, writes its
+//     phase B: group 1 issues its MFMAs      |          next slab to LDS, issues the loads after that) -- and vice versa.
+// All waits on global loads sit at the START of a staging phase, when everything outstanding was issued a full iteration
+// earlier, so hipcc's conservative vmcnt(0) costs nothing.  With one workgroup per CU there are 160 KB of LDS: each
+// group's slab is double-buffered (the next work item's slab is written while the current one is being read).
+// Data layout, fragment maps, both arithmetic variants (exact fp32 / bf16x3 split precision) and the epilogue are those
+// of conv_gemm.hip.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace e2etts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#ifdef E2ETTS_DIAG
+__device__ unsigned long long g_pp_diag[16];
+#define PP_STAMP(var)                                                                  \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#define PP_ADD(slot, a, b) dsum[slot] += (b) - (a)
+#else
+#define PP_STAMP(var) do {} while (0)
+#define PP_ADD(slot, a, b) do {} while (0)
+#endif
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;
+constexpr int MAX_HALO = 64;
+constexpr int BM = 128, BN = 128, WM = 64, WN = 64;
+constexpr int MT = WM / 32, NT = WN / 32;
+constexpr int AROWS = (BM + MAX_HALO + 31) / 32;  // slab rows staged per thread of a group (upper bound)
+constexpr int BROWS = BN / 2 / 32;                // weight-tile rows staged per thread (each group stages half the tile)
+constexpr int ELD = WN + 4;
+
+__device__ __forceinline__ float4 lrelu4(float4 v, float slope) {
+  v.x = fmaxf(v.x, v.x * slope);
+  v.y = fmaxf(v.y, v.y * slope);
+  v.z = fmaxf(v.z, v.z * slope);
+  v.w = fmaxf(v.w, v.w * slope);
+  return v;
+}
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const bf16x2 r = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  hi.x = pack_bf16(v.x, v.y);
+  hi.y = pack_bf16(v.z, v.w);
+  const float hx = __builtin_bit_cast(float, hi.x << 16), hy = __builtin_bit_cast(float, hi.x & 0xffff0000u);
+  const float hz = __builtin_bit_cast(float, hi.y << 16), hw = __builtin_bit_cast(float, hi.y & 0xffff0000u);
+  lo.x = pack_bf16(v.x - hx, v.y - hy);
+  lo.y = pack_bf16(v.z - hz, v.w - hw);
+}
+
+template <bool X3>
+__global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvParams p, const int pairs_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int halo = p.dil * (p.KW - 1);
+  const int arows = BM + halo;
+  const int slab = arows * LDK;  // floats per slab buffer
+  const int tid = threadIdx.x;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 8);  // group: waves 0-3 / 4-7 (w and w + 4 share a SIMD)
+  const int gt = tid & 255;
+  const int lane = gt & 63, wave = gt >> 6;                // wave inside its group
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int lrow = gt >> 3, lc4 = (gt & 7) * 4;
+  float* As0 = smem + (g * 2) * slab;   // this group's slab buffers: As0, As0 + slab
+  float* Bs = smem + 4 * slab;          // two weight-tile buffers shared by both groups
+
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.y * BN;
+  const int mtiles = (p.T + BM - 1) / BM;
+  const int npairs_all = (mtiles + 1) / 2;
+  const int pair0 = blockIdx.x * pairs_per_block;
+  const int npair = min(pairs_per_block, npairs_all - pair0);
+  const float* in_b = p.in + (long long)b * p.in_bs;
+  const bool split = p.x3 != 2;
+  const int nchunk = (p.Cin + BK - 1) / BK;
+  const int KC = X3 ? p.KW * nchunk * BK : p.KW * p.Cin;
+  const int nitem = npair * nchunk;       // work items of ONE group (both groups walk the same (chunk, tap) sequence)
+  const int niter = nitem * p.KW;
+  auto tile_of = [&](int item) { return 2 * (pair0 + item / nchunk) + g; };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // ---- staging state (see conv_gemm.hip for the rationale of unconditional buffer loads)
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((long long)p.Cout * KC * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t in_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((long long)p.T * p.in_ld * 4), 0x00020000);
+  float4 breg[BROWS], areg[AROWS];
+  int wvoff[BROWS];
+  bool wok[BROWS];
+#pragma unroll
+  for (int i = 0; i < BROWS; ++i) {
+    const int n = n0 + g * (BN / 2) + lrow + i * 32;
+    wok[i] = n < p.Cout;
+    wvoff[i] = (min(n, p.Cout - 1) * KC + lc4) * 4;
+  }
+  const bool w_all_ok = n0 + BN <= p.Cout;
+  const bool ragged = (p.Cin % BK) != 0;
+  int avoff[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) avoff[i] = ((lrow + i * 32) * p.in_ld + lc4) * 4;
+  const int cmax = p.Cin - 4;
+  bool b_cok = true, b_mask = false, a_cok = true, a_edge = false, a_valid = false;
+  int a_tbase = 0;
+
+  auto load_b = [&](int it) {  // this group's half of the weight tile of iteration `it` -> breg
+    const int item = it / p.KW, j = it - item * p.KW;
+    const int chunk = item % nchunk;
+    const int c = chunk * BK + lc4;
+    const bool partial = !X3 && ragged && chunk == nchunk - 1;
+    b_cok = !partial || c < p.Cin;
+    b_mask = partial || !w_all_ok;
+    const int soff = (X3 ? (j * nchunk + chunk) * BK : j * p.Cin + chunk * BK) * 4;
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i)
+      breg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wvoff[i], soff, 0));
+  };
+  auto store_b = [&](int buf) {
+    float* dst = Bs + buf * (BN * LDK) + g * (BN / 2) * LDK;
+    if (b_mask) {
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i)
+        if (!(wok[i] && b_cok)) breg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(dst + (lrow + i * 32) * LDK + lc4) = breg[i];
+  };
+  auto load_a = [&](int item) {  // slab of work item `item` of this group -> areg
+    const int tile = tile_of(item), chunk = item % nchunk;
+    a_valid = tile < mtiles;
+    if (!a_valid) return;
+    const int c = chunk * BK + lc4;
+    a_cok = c < p.Cin;
+    a_tbase = tile * BM - p.pad;
+    a_edge = a_tbase < 0 || a_tbase + AROWS * 32 > p.T || (ragged && chunk == nchunk - 1);
+    if (!a_edge) {
+      const int soff = (a_tbase * p.in_ld + chunk * BK) * 4;
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i)
+        areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff[i], soff, 0));
+    } else {
+      const int cc = min(c, cmax);
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int t = min(max(a_tbase + lrow + i * 32, 0), p.T - 1);
+        areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (t * p.in_ld + cc) * 4, 0, 0));
+      }
+    }
+  };
+  auto store_a = [&](float* As) {
+    if (!a_valid) return;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int r = lrow + i * 32;
+      float4 v = areg[i];
+      if (a_edge) {
+        const int t = a_tbase + r;
+        if (!(a_cok && t >= 0 && t < p.T)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (p.in_slope != 1.0f) v = lrelu4(v, p.in_slope);
+      if (r < arows) {
+        if constexpr (X3) {
+          uint2 hi, lo;
+          split4(v, hi, lo);
+          *reinterpret_cast<uint2*>(As + r * LDK + (lc4 >> 1)) = hi;
+          *reinterpret_cast<uint2*>(As + r * LDK + 16 + (lc4 >> 1)) = lo;
+        } else {
+          *reinterpret_cast<float4*>(As + r * LDK + lc4) = v;
+        }
+      }
+    }
+  };
+
+  // ---- epilogue (float4 through a wave-private LDS patch; see conv_gemm.hip)
+  const bool vec_ok = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && ((p.out_bs & 3) == 0) && (((uintptr_t)p.out & 15) == 0) &&
+                      (!p.res || ((p.res_ld % 4 == 0) && ((p.res_bs & 3) == 0) && (((uintptr_t)p.res & 15) == 0))) &&
+                      (!p.bias || (((uintptr_t)p.bias & 15) == 0));
+  const int len = p.lens ? p.lens[b] : p.T;
+  float* out_b = p.out + (long long)b * p.out_bs;
+  const float* res_b = p.res ? p.res + (long long)b * p.res_bs : nullptr;
+  constexpr int LPR = WN / 4, RPP = 64 / LPR, PASSES = 16 / RPP;
+  const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+  const int ecol = n0 + wn * WN + pc4;
+  const bool ecol_ok = ecol < p.Cout;
+  const int ecol_c = min(ecol, max(p.Cout - 4, 0));
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec_ok && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + ecol_c);
+  const float eslope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LRELU ? p.act_slope : 1.f);
+
+  auto epilogue_vec = [&](int tile, float* patch_base, auto has_res) {
+    constexpr bool RES = decltype(has_res)::value;
+    const int t0 = tile * BM + wm * WM;
+    float* patch = patch_base + wave * (16 * ELD);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float4 resv[2][PASSES];  // residual rows of this 32-row block, requested before its transposes
+      if constexpr (RES) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) {
+            const int t = min(t0 + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
+            resv[hh][ps] = *reinterpret_cast<const float4*>(res_b + (long long)t * p.res_ld + ecol_c);
+          }
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = hh * 8 + rr;
+            const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;
+            patch[row * ELD + n * 32 + li] = acc[m][n][r];
+          }
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int row = ps * RPP + prow;
+          const int t = t0 + m * 32 + hh * 16 + row;
+          float4 v = *reinterpret_cast<const float4*>(patch + row * ELD + pc4);
+          v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+          v.x = fmaxf(v.x, v.x * eslope); v.y = fmaxf(v.y, v.y * eslope);
+          v.z = fmaxf(v.z, v.z * eslope); v.w = fmaxf(v.w, v.w * eslope);
+          if (p.act == ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+          if constexpr (RES) {
+            const float4 rv = resv[hh][ps];
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+          }
+          if (t >= len) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          const bool ok = t < p.T && ecol_ok;
+          float4* o = reinterpret_cast<float4*>(out_b + (long long)min(t, p.T - 1) * p.out_ld + ecol_c);
+          if (p.accumulate) {
+            const float4 ov = *o;
+            v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+          }
+          if (p.out_div != 1.0f) {
+            v.x = v.x / p.out_div; v.y = v.y / p.out_div; v.z = v.z / p.out_div; v.w = v.w / p.out_div;
+          }
+          if (ok) *o = v;
+        }
+      }
+    }
+  };
+  auto epilogue = [&](int tile, float* patch_base) {
+    if (tile < mtiles) {
+      if (vec_ok) {
+        if (res_b) epilogue_vec(tile, patch_base, std::true_type{});
+        else epilogue_vec(tile, patch_base, std::false_type{});
+      } else {
+        const int t0 = tile * BM;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int col = n0 + wn * WN + n * 32 + li;
+          if (col >= p.Cout) continue;
+          const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int t = t0 + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (t >= p.T) continue;
+              float v = acc[m][n][r] + bias;
+              v = p.act == ACT_TANH ? tanhf(v) : fmaxf(v, v * eslope);
+              if (res_b) v += res_b[(long long)t * p.res_ld + col];
+              if (t >= len) v = 0.f;
+              float* o = out_b + (long long)t * p.out_ld + col;
+              if (p.accumulate) v += *o;
+              if (p.out_div != 1.0f) v = v / p.out_div;
+              *o = v;
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  };
+
+  // ---- MFMA phase of one (chunk, tap) iteration for this group
+  auto mfma_phase = [&](const float* As, const float* Bt, int j) {
+    const float* a_base = As + (wm * WM + li + j * p.dil) * LDK + lh * 4;
+    const float* b_base = Bt + (wn * WN + li) * LDK + lh * 4;
+    // The group that issues MFMAs has the SIMD to itself (its partner wave is staging or parked at the barrier), so every
+    // LDS latency inside the phase is exposed: all operand fragments of the iteration are requested up front and the
+    // MFMAs follow behind counted lgkmcnt waits.
+    if constexpr (X3) {
+      bf16x8 ah[BK / 16][MT], al[BK / 16][MT], bh[BK / 16][NT], bl[BK / 16][NT];
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          ah[ks][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + ks * 8));
+          al[ks][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + 16 + ks * 8));
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          bh[ks][n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + ks * 8));
+          bl[ks][n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + 16 + ks * 8));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if (split) {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][m], bh[ks][n], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][m], bl[ks][n], acc[m][n], 0, 0, 0);
+            }
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][m], bh[ks][n], acc[m][n], 0, 0, 0);
+          }
+    } else {
+      float4 af[BK / 8][MT], bf[BK / 8][NT];
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[q][m] = *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + q * 8);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[q][n] = *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + q * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][m].x, bf[q][n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][m].y, bf[q][n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][m].z, bf[q][n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][m].w, bf[q][n].w, acc[m][n], 0, 0, 0);
+          }
+    }
+  };
+
+  // ---- prologue: weight tiles 0 (published) and 1 (in registers), slab of item 0 (published); for KW == 1 the slab
+  //      pipeline runs two items deep (an item is a single iteration), so the slab of item 1 is requested as well
+  const bool one_tap = p.KW == 1;
+  load_b(0);
+  store_b(0);
+  if (niter > 1) load_b(1);
+  load_a(0);
+  store_a(As0);
+  if (one_tap && nitem > 1) load_a(1);
+  __syncthreads();
+
+  // Staging phase of iteration `it` (item `item`, tap j).  Everything it waits for was requested one iteration ago.
+  auto staging = [&](int it, int item, int j) {
+    if (it + 1 < niter) store_b((it + 1) & 1);                           // tile it+1: its buffer was last read in iteration it-1
+    const bool last_tap = j == p.KW - 1;
+    if (last_tap && item + 1 < nitem) store_a(As0 + ((item + 1) & 1) * slab);  // slab of the next item, other buffer
+    if (it + 2 < niter) load_b(it + 2);
+    const int want = item + (one_tap ? 2 : 1);
+    if (j == 0 && want < nitem) load_a(want);
+  };
+
+  int item = 0, j = 0;
+#ifdef E2ETTS_DIAG
+  unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
+#endif
+  for (int it = 0; it < niter; ++it) {
+    const float* As = As0 + (item & 1) * slab;
+    const float* Bt = Bs + (it & 1) * (BN * LDK);
+    const bool my_valid = tile_of(item) < mtiles;
+    PP_STAMP(ta);
+    if (g == 0) { if (my_valid) mfma_phase(As, Bt, j); } else { staging(it, item, j); }
+    PP_STAMP(tb); PP_ADD(0, ta, tb);
+    __syncthreads();
+    PP_STAMP(ta); PP_ADD(1, tb, ta);
+    if (g == 0) { staging(it, item, j); } else { if (my_valid) mfma_phase(As, Bt, j); }
+    PP_STAMP(tb); PP_ADD(2, ta, tb);
+    __syncthreads();
+    PP_STAMP(ta); PP_ADD(3, tb, ta);
+    if (++j == p.KW) {
+      j = 0;
+      if ((item + 1) % nchunk == 0) {  // tile finished for both groups: the finished item's slab buffer hosts the patches
+        epilogue(tile_of(item), As0 + (item & 1) * slab);
+        __syncthreads();
+        PP_STAMP(tb); PP_ADD(4, ta, tb);
+      }
+      ++item;
+    }
+  }
+#ifdef E2ETTS_DIAG
+  if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && (gt == 0)) {
+    for (int i = 0; i < 5; ++i) g_pp_diag[g * 8 + i] = dsum[i];
+    g_pp_diag[g * 8 + 7] = niter;
+  }
+#endif
+}
+
+template <bool X3>
+const char* launch_pp(const ConvParams& p, hipStream_t s) {
+  const int halo = p.dil * (p.KW - 1);
+  const size_t lds = (size_t)(4 * (BM + halo) * LDK + 2 * BN * LDK) * sizeof(float);
+  if (lds > 160 * 1024) return "conv_pp: LDS tile exceeds 160 KiB";
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return "conv_pp: cannot raise the dynamic LDS limit";
+    attr_set = true;
+  }
+  const int mtiles = (p.T + BM - 1) / BM;
+  const int npairs = (mtiles + 1) / 2;
+  const int ntiles = (p.Cout + BN - 1) / BN;
+  const long long total = (long long)npairs * ntiles * p.B;
+  int ppb = (int)(total / (256 * 3));  // ~3 rounds of one workgroup per CU, each walking up to 8 tile pairs
+  ppb = ppb < 1 ? 1 : (ppb > 8 ? 8 : ppb);
+  if (ppb > npairs) ppb = npairs;
+  dim3 grid((npairs + ppb - 1) / ppb, ntiles, p.B);
+  hipLaunchKernelGGL((conv_pp_kernel<X3>), grid, dim3(512), lds, s, p, ppb);
+  return hipGetLastError() == hipSuccess ? nullptr : "conv_pp: launch failed";
+}
+
+}  // namespace
+
+#ifdef E2ETTS_DIAG
+void conv_pp_read_diag(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_diag), sizeof(g_pp_diag)); }
+#endif
+
+// Shape / alignment checks are done by launch_conv_gemm before it forwards here.
+const char* launch_conv_pp(const ConvParams& p, hipStream_t s) {
+  return p.x3 ? launch_pp<true>(p, s) : launch_pp<false>(p, s);
+}
+
+}  // namespace e2etts

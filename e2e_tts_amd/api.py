@@ -8,8 +8,9 @@ Same constructor arguments, attributes (``hop_length``, ``sample_rate``, ``max_w
   only device->host traffic per batch is the int16 PCM (the reference copies fp32 audio, API/utils.py:145);
 * ``input_parse`` sorts with a *stable* descending sort (torch.sort(descending=True) at :84 leaves the order of
   equal-length sentences unspecified; batches and audio are identical, only ties may be numbered differently);
-* text -> phoneme ids is pluggable (``text_to_sequence=``): the reference's g2p package is the next item of the
-  scope table (SURVEY.md 8(f)) and, as shipped, cannot run (cleaners.py:12,26-30 recurses with a bad kwarg);
+* text -> phoneme ids defaults to ``e2e_tts_amd.g2p.text_to_sequence`` (a working restatement of the reference's
+  Vietnamese g2p, pinned by a fixture converted with the reference's own code; the reference's ``text_to_sequence``
+  cannot run as shipped: cleaners.py:12,26-30 recurses with a bad kwarg) and stays pluggable (``text_to_sequence=``);
 * no network call to a text normaliser (API/inference.py:28-33 swallows its failure anyway), no upload.
 """
 from __future__ import annotations
@@ -58,6 +59,9 @@ class TTS:
         self.sample_rate = self.config["audio"]["signal"]["sampling_rate"]
         self.max_wav_value = 32768.0
         self.max_len = max_len
+        if text_to_sequence is None:
+            from .g2p import text_to_sequence as _default_g2p
+            text_to_sequence = _default_g2p
         self.text_to_sequence = text_to_sequence
         self._acoustic = None
         self._vocoder = None

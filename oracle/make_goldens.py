@@ -339,6 +339,69 @@ def case_host_loop():
     save("host_loop", **arrays)
 
 
+def case_g2p():
+    """Vietnamese grapheme -> phoneme front-end (reference e2e_tts/models/g2p/g2p.py:58-176, symbols.py:19-50,
+    __init__.py:5-31), run from the reference source.  Two absent third-party imports get stand-ins: `g2p_en.G2p`
+    (English fallback, never reached: dict/foreign_words.json is empty) and `unidecode.unidecode`, for which NFD
+    decomposition minus combining marks (+ d-stroke -> d) is used -- identical to unidecode on the Vietnamese alphabet.
+    `text_to_sequence` itself cannot run as shipped (cleaners.py:12,26-30 shadows the import and recurses), so the
+    fixture calls what it evidently intends: normalize_phonemes(text.lower(), is_training=False) + the symbol -> id map."""
+    print("[g2p]", flush=True)
+    import importlib
+    import types
+    import unicodedata
+    g2p_en = types.ModuleType("g2p_en")
+    g2p_en.G2p = type("G2p", (), {"__call__": lambda self, t: []})
+    ud = types.ModuleType("unidecode")
+
+    def unidecode(x):
+        x = x.replace("\u0111", "d").replace("\u0110", "D")
+        return "".join(c for c in unicodedata.normalize("NFD", x) if not unicodedata.combining(c))
+    ud.unidecode = unidecode
+    sys.modules["g2p_en"], sys.modules["unidecode"] = g2p_en, ud
+    sys.path.insert(0, os.path.join(REF, "e2e_tts", "models"))
+    ref_g2p = importlib.import_module("g2p.g2p")
+    ref_sym = importlib.import_module("g2p.symbols")
+    symbols = list(ref_sym.symbols)
+    sym2id = {s: i for i, s in enumerate(symbols)}
+    words = [w for w in ref_g2p.vn_words]
+    rng = np.random.Generator(np.random.PCG64(9))
+    pick = sorted(set(rng.choice(len(words), size=1500, replace=False).tolist()))
+    sample, phon = [], []
+    skipped = 0
+    for i in pick:
+        try:
+            ph = ref_g2p.vi_convert(words[i])
+        except Exception:   # a handful of dictionary entries are not single syllables the converter accepts
+            skipped += 1
+            continue
+        sample.append(words[i])
+        phon.append(" ".join(ph))
+    print(f"    {len(sample)} words ({skipped} raise in the reference and are left out)")
+    sentences = [
+        "xin ch\u00e0o vi\u1ec7t nam",
+        "h\u00f4m nay tr\u1eddi \u0111\u1eb9p , ch\u00fang ta \u0111i ch\u01a1i nh\u00e9 .",
+        "qu\u1ed1c gia , gi\u00e1o d\u1ee5c v\u00e0 khoa-h\u1ecdc c\u00f4ng-ngh\u1ec7 ?",
+        "ngh\u1ec7 thu\u1eadt t\u1ed5ng h\u1ee3p ti\u1ebfng n\u00f3i",
+        "u\u1ed1ng n\u01b0\u1edbc nh\u1edb ngu\u1ed3n !",
+        "kh\u00f4ng-gian th\u1eddi-gian",
+        "a",
+    ]
+    import contextlib
+    import io
+    sent_ids, sent_ph = [], []
+    for t in sentences:
+        with contextlib.redirect_stdout(io.StringIO()):
+            seq, boundaries = ref_g2p.normalize_phonemes(t.lower(), is_training=False)
+        sent_ph.append(" ".join(seq))
+        sent_ids.append(np.array([sym2id[w[:-1] if w.startswith("@") and w[-1].isdigit() else w] for w in seq], np.int64))
+    arrays = dict(symbols=np.array(symbols), words=np.array(sample), phonemes=np.array(phon), sentences=np.array(sentences),
+                  sentence_phonemes=np.array(sent_ph))
+    for i, ids in enumerate(sent_ids):
+        arrays[f"ids{i}"] = ids
+    save("g2p", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -349,6 +412,7 @@ def main():
     jobs = {
         "tables": lambda: case_tables(models),
         "host_loop": case_host_loop,
+        "g2p": case_g2p,
         "voc_micro_tiny": lambda: case_vocoder_micro(models),
         "tiny_b3": lambda: case_model(models, "tiny_b3", tiny, "varied", [23, 17, 9], 1, (1.0, 1.0, 1.0), 100, 2e-3, "full"),
         "tiny_long": lambda: case_model(models, "tiny_long", tiny, "varied", [70, 33], 2, (1.0, 1.0, 1.0), 200, 2e-3, "full"),

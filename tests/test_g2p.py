@@ -1,0 +1,37 @@
+"""CPU tests of the text front-end against the fixture converted by the reference's own g2p code."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from e2e_tts_amd import g2p
+
+
+def test_symbol_table_matches_reference():
+    g = load_golden("g2p")
+    assert g2p.symbols == [str(s) for s in g["symbols"]]
+    assert len(g2p.symbols) == 131
+
+
+def test_syllables_match_reference():
+    g = load_golden("g2p")
+    bad = [(w, " ".join(g2p.vi_convert(str(w))), str(p)) for w, p in zip(g["words"], g["phonemes"])
+           if " ".join(g2p.vi_convert(str(w))) != str(p)]
+    assert not bad, bad[:10]
+
+
+def test_sentences_and_ids_match_reference():
+    g = load_golden("g2p")
+    for i, (s, ph) in enumerate(zip(g["sentences"], g["sentence_phonemes"])):
+        seq, _ = g2p.normalize_phonemes(str(s).lower(), is_training=False)
+        assert " ".join(seq) == str(ph)
+        np.testing.assert_array_equal(g2p.text_to_sequence(str(s)), g[f"ids{i}"])
+    assert g2p.text_to_sequence("Xin   CHÀO") == g2p.text_to_sequence("xin chào")
+    assert g2p.sequence_to_text(g2p.text_to_sequence("a")) == "A_0 </S>"
+
+
+def test_edge_cases():
+    assert g2p.text_to_sequence("a - b")[-1] == g2p._symbol_to_id["</S>"]      # lone hyphen: skipped (the reference raises)
+    with pytest.raises(KeyError):
+        g2p.text_to_sequence("zz")                                             # no nucleus: "_0" is not a symbol (same in the reference)
+    seq = g2p.text_to_sequence("một , hai .")
+    assert seq.count(g2p._symbol_to_id["<SILENT>"]) == 1 and seq[-1] == g2p._symbol_to_id["</S>"]

@@ -85,8 +85,12 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
 //             bf16's 2^-8; measured on the vocoder: wav mean-L1 9e-7 vs fp64, against 6e-8 for fp32 and 5e-4 for
 //             plain bf16).  An LDS row holds one 32-channel chunk as [32 bf16 hi | 32 bf16 lo | pad] = the same 144
 //             bytes as the fp32 row; activations are split while staging, weights arrive pre-split from the packer.
-template <int BM, int BN, int WM, int WN, bool X3>
+// MODE 0: exact fp32; 1: bf16x3 split precision; 2: plain bf16 (hi x hi only).  A compile-time mode keeps the MFMA block one
+// straight basic block (a runtime flag put a branch between every few MFMAs).
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
+  constexpr bool X3 = MODE != 0;
+  constexpr bool SPLIT = MODE == 1;
   constexpr int NWN = BN / WN;
   constexpr int MT = WM / 32, NT = WN / 32;
   static_assert((BM / WM) * NWN == 4, "4 wavefronts per workgroup");
@@ -113,7 +117,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   const int tile0 = blockIdx.x * tiles_per_block;
   const int ntile = min(tiles_per_block, mtiles - tile0);
   const float* in_b = p.in + (long long)b * p.in_bs;
-  const bool split = p.x3 != 2;  // uniform
   const int nchunk = (p.Cin + BK - 1) / BK;
   const int KC = X3 ? p.KW * nchunk * BK : p.KW * p.Cin;  // X3 weights: [Cout][KW][nchunk][32 words], chunk-padded
   const int nitem = ntile * nchunk;
@@ -248,18 +251,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
     constexpr bool RES = decltype(has_res)::value;
     const int t0 = tile * BM + wm * WM;
     float* patch = As + wave * (16 * ELD);  // wave-private: no workgroup barrier between its write and read
-    float4 resv[MT * 2][PASSES];
-    if constexpr (RES) {
-#pragma unroll
-      for (int blk = 0; blk < MT * 2; ++blk)
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-          const int t = min(t0 + blk * 16 + ps * RPP + prow, p.T - 1);
-          resv[blk][ps] = *reinterpret_cast<const float4*>(res_b + (long long)t * p.res_ld + ecol_c);
-        }
-    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+      float4 resv[2][PASSES];  // residual rows of this 32-row block, requested before its transposes
+      if constexpr (RES) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) {
+            const int t = min(t0 + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
+            resv[hh][ps] = *reinterpret_cast<const float4*>(res_b + (long long)t * p.res_ld + ecol_c);
+          }
+      }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
           v.z = fmaxf(v.z, v.z * eslope); v.w = fmaxf(v.w, v.w * eslope);
           if (p.act == ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
           if constexpr (RES) {
-            const float4 rv = resv[m * 2 + hh][ps];
+            const float4 rv = resv[hh][ps];
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
           }
           if (t >= len) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            if (split) {  // the two cross terms; skipped in plain-bf16 mode (x3 == 2)
+            if constexpr (SPLIT) {  // the two cross terms; absent in plain-bf16 mode
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
               acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
             }
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, bool X3>
+template <int BM, int BN, int WM, int WN, int MODE>
 const char* launch_cfg(const ConvParams& p, hipStream_t s) {
   const int halo = p.dil * (p.KW - 1);
   const size_t lds = (size_t)((BM + halo) * LDK + 2 * BN * LDK) * sizeof(float);
@@ -454,7 +457,7 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
   tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
   if (tpb > mtiles) tpb = mtiles;
   dim3 grid((mtiles + tpb - 1) / tpb, ntiles, p.B);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, X3>), grid, dim3(256), lds, s, p, tpb);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE>), grid, dim3(256), lds, s, p, tpb);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
 }
 
@@ -481,17 +484,23 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   if (p.in_ld < p.Cin || p.out_ld < p.Cout || (p.res && p.res_ld < p.Cout)) return "conv_gemm: row stride < channels";
   if (p.dil * (p.KW - 1) > MAX_HALO) return "conv_gemm: dilation * (KW - 1) exceeds the slab halo limit";
   if (p.pad < 0 || p.pad > p.dil * (p.KW - 1)) return "conv_gemm: pad out of range";
+  if (p.x3 < 0 || p.x3 > 2) return "conv_gemm: x3 must be 0 (fp32), 1 (bf16x3) or 2 (bf16)";
   if (p.in_slope < 0.f || p.in_slope > 1.f) return "conv_gemm: in_slope must lie in [0, 1]";
   if ((long long)p.T * p.in_ld * 4 >= (1LL << 31) || (long long)p.Cout * p.KW * ((p.Cin + 31) / 32 * 32) * 4 >= (1LL << 31))
     return "conv_gemm: one utterance / the weight matrix must stay below 2 GiB (32-bit buffer offsets)";
-  if (p.x3) {
-    if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, true>(p, s);
-    if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, true>(p, s);
-    return launch_cfg<256, 32, 64, 32, true>(p, s);
+  if (p.x3 == 1) {
+    if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 1>(p, s);
+    if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 1>(p, s);
+    return launch_cfg<256, 32, 64, 32, 1>(p, s);
   }
-  if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, false>(p, s);
-  if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, false>(p, s);
-  return launch_cfg<256, 32, 64, 32, false>(p, s);
+  if (p.x3 == 2) {
+    if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 2>(p, s);
+    if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 2>(p, s);
+    return launch_cfg<256, 32, 64, 32, 2>(p, s);
+  }
+  if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 0>(p, s);
+  if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 0>(p, s);
+  return launch_cfg<256, 32, 64, 32, 0>(p, s);
 }
 
 }  // namespace e2etts

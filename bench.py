@@ -38,28 +38,32 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+CPU_THREADS = 16  # measured on the GPU box's 256-core host: the oracle is fastest at 16 threads (32: -18 %, 64: -50 %, 256: -94 %)
+CPU_BATCH = 8
+
+
 def cpu_baseline(cfg, stats, ac_state, voc_state):
-    """The numpy oracle (a port of the reference's CPU path) timed on this host's cores on a bounded sample
-    of the same workload: B = 1, L = 48 phonemes -> 288 frames = 73 728 samples (3.3 s of audio)."""
+    """The oracle (numpy + its plain-C / OpenMP conv1d: a port of the reference's CPU path) timed on this host's cores on a
+    bounded sample of the same workload: B = 8 of the benchmark's 32 utterances (L = 128 phonemes -> 768 frames each,
+    1 572 864 samples = 71 s of audio), BLAS and OpenMP pools limited to CPU_THREADS threads."""
+    from threadpoolctl import threadpool_limits
     from oracle import ref_numpy as orc
-    L = 48
+    L = PHONEMES
     rng = np.random.Generator(np.random.PCG64(1))
-    ids = rng.integers(4, 131, size=(1, L)).astype(np.int64)
-    lens = np.array([L], np.int64)
+    ids = rng.integers(4, 131, size=(CPU_BATCH, L)).astype(np.int64)
+    lens = np.full((CPU_BATCH,), L, np.int64)
     ac = orc.AcousticOracle(ac_state, cfg, stats)
     voc = orc.VocoderOracle(voc_state, cfg)
-    t0 = time.perf_counter()
-    (mel, mel_post, dur), mel_lens = ac.inference(np.array([1]), ids, lens)
-    wav = voc.forward(mel_post.transpose(0, 2, 1))
-    dt = time.perf_counter() - t0
+    with threadpool_limits(limits=CPU_THREADS):
+        t0 = time.perf_counter()
+        (mel, mel_post, dur), mel_lens = ac.inference(np.array([1]), ids, lens)
+        wav = voc.forward(mel_post.transpose(0, 2, 1))
+        dt = time.perf_counter() - t0
     samples = int(mel_lens.sum()) * cfg["audio"]["stft"]["hop_length"]
-    assert wav.shape[-1] == samples
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    return {"value": samples / dt, "unit": "audio samples/s", "cores": cores, "kind": "port",
-            "sample": f"numpy oracle, B=1 L={L} -> T={int(mel_lens[0])} frames ({samples} samples), {dt:.1f} s wall"}
+    assert wav.shape[0] * wav.shape[-1] == samples
+    backend = "numpy + C/OpenMP conv1d" if orc._c_conv() else "numpy only"
+    return {"value": samples / dt, "unit": "audio samples/s", "cores": CPU_THREADS, "kind": "port",
+            "sample": f"oracle ({backend}), B={CPU_BATCH} L={L} -> T={int(mel_lens[0])} frames each ({samples} samples), {dt:.1f} s wall"}
 
 
 def main():

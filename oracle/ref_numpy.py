@@ -46,14 +46,49 @@ def linear(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray]) -> np.ndarray:
     return y
 
 
+_C_CONV = None
+
+
+def _c_conv():
+    """Optional plain-C / OpenMP backend of conv1d (oracle/conv1d.c, built by __graft_entry__.build()); fp32 only.
+    Same arithmetic up to summation order; the numpy path below is the fallback and the float64 path."""
+    global _C_CONV
+    if _C_CONV is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libref_conv1d.so")
+        _C_CONV = False
+        if os.path.exists(path) and not os.environ.get("E2ETTS_ORACLE_NUMPY"):
+            try:
+                lib = ctypes.CDLL(path)
+                lib.ref_conv1d_f32.restype = ctypes.c_int
+                lib.ref_conv1d_f32.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7
+                _C_CONV = lib
+            except OSError:
+                _C_CONV = False
+    return _C_CONV
+
+
 def conv1d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], padding: int = 0, dilation: int = 1,
            chunk: int = 8192) -> np.ndarray:
     """torch.nn.Conv1d (stride 1, zero padding).  x [B, Cin, T], w [Cout, Cin, K] -> [B, Cout, T'].
 
-    One [Cout, K*Cin] x [K*Cin, n] product per chunk of n output positions (im2col by chunks keeps
-    the BLAS call large even when Cin is 32 and the column buffer small enough to stay in cache).
+    fp32 inputs go to the C backend when it is built; otherwise (and for float64) numpy: one [Cout, K*Cin] x [K*Cin, n]
+    product per chunk of n output positions (im2col by chunks keeps the BLAS call large even when Cin is 32 and the
+    column buffer small enough to stay in cache).
     """
     B, Cin, T = x.shape
+    lib = _c_conv() if (x.dtype == np.float32 and w.dtype == np.float32) else None
+    if lib:
+        Cout, _, K = w.shape
+        Tout = T + 2 * padding - dilation * (K - 1)
+        xc, wc = np.ascontiguousarray(x), np.ascontiguousarray(w)
+        bc = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
+        out = np.empty((B, Cout, Tout), dtype=np.float32)
+        rc = lib.ref_conv1d_f32(xc.ctypes.data, wc.ctypes.data, None if bc is None else bc.ctypes.data, out.ctypes.data,
+                                B, Cin, T, Cout, K, padding, dilation)
+        if rc == 0:
+            return out
     Cout, _, K = w.shape
     xp = np.zeros((B, Cin, T + 2 * padding), dtype=x.dtype)
     xp[:, :, padding:padding + T] = x
@@ -77,8 +112,10 @@ def conv_transpose1d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stri
     B, Cin, T = x.shape
     _, Cout, K = w.shape
     full = np.zeros((B, Cout, (T - 1) * stride + K), dtype=x.dtype)
+    wt = np.ascontiguousarray(w.transpose(2, 1, 0))  # [K, Cout, Cin]: contiguous per tap, or matmul leaves BLAS
+    xc = np.ascontiguousarray(x)
     for k in range(K):
-        full[:, :, k:k + (T - 1) * stride + 1:stride] += np.matmul(w[:, :, k].T, x)
+        full[:, :, k:k + (T - 1) * stride + 1:stride] += np.matmul(wt[k], xc)
     out = full[:, :, padding:full.shape[2] - padding]
     if b is not None:
         out = out + b[None, :, None]
@@ -93,7 +130,8 @@ def layer_norm(x: np.ndarray, gamma: np.ndarray, beta: np.ndarray, eps: float) -
 
 
 def leaky_relu(x: np.ndarray, slope: float) -> np.ndarray:
-    return np.where(x >= 0, x, x * x.dtype.type(slope))
+    """F.leaky_relu for 0 <= slope <= 1: max(x, slope * x) (same values as where(x >= 0, x, slope * x))."""
+    return np.maximum(x, x * x.dtype.type(slope))
 
 
 def softmax_lastdim(x: np.ndarray) -> np.ndarray:

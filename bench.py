@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--workload", choices=("fixed", "mixed"), default="fixed",
+                    help="fixed: the headline B=32 x L=128 batch; mixed: BASELINE config 3 (32 utterances of 40..200 phonemes, "
+                         "padded to 200 -> T=1200), value = VALID samples/s")
     ap.add_argument("--precision", choices=("fp32", "bf16x3"), default="bf16x3",
                     help="vocoder arithmetic: exact fp32 MFMA, or split-precision bf16x3 MFMA (default; wav error ~1e-6)")
     args = ap.parse_args()
@@ -132,10 +135,21 @@ def main():
 
     B, L = args.batch, PHONEMES
     rng = np.random.Generator(np.random.PCG64(1000 + rank))
-    ids = torch.from_numpy(rng.integers(4, 131, size=(B, L)).astype(np.int64)).cuda()
-    lens = torch.full((B,), L, dtype=torch.int64, device="cuda")
+    if args.workload == "mixed":   # lengths linspace(40, 200, 32) shuffled, padded to 200
+        lens_np = np.round(np.linspace(40, 200, B)).astype(np.int64)
+        np.random.Generator(np.random.PCG64(2)).shuffle(lens_np)
+        L = int(lens_np.max())
+        ids_np = np.zeros((B, L), np.int64)
+        for b, n in enumerate(lens_np):
+            ids_np[b, :n] = rng.integers(4, 131, size=n)
+    else:
+        lens_np = np.full((B,), L, np.int64)
+        ids_np = rng.integers(4, 131, size=(B, L)).astype(np.int64)
+    ids = torch.from_numpy(ids_np).cuda()
+    lens = torch.from_numpy(lens_np).cuda()
     spk = torch.tensor([1], dtype=torch.int64, device="cuda")
     T = L * FRAMES_PER_PHONEME
+    valid_frames = int(lens_np.sum()) * FRAMES_PER_PHONEME
     pcm = torch.empty((B, T * hop), dtype=torch.int16, device="cuda")
     mel_lens = torch.empty((B,), dtype=torch.int64, device="cuda")
 
@@ -146,7 +160,7 @@ def main():
     for _ in range(args.warmup):
         t = step()
         assert t == T, (t, T)
-    assert int(mel_lens.min().item()) == T and int(mel_lens.max().item()) == T
+    assert int(mel_lens.sum().item()) == valid_frames and int(mel_lens.max().item()) == T
 
     def barrier():
         torch.cuda.synchronize()
@@ -168,7 +182,7 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    samples_per_step = world * B * T * hop  # every rank synthesises B utterances of T valid frames
+    samples_per_step = world * valid_frames * hop  # valid samples only (padding excluded)
     value = samples_per_step * args.steps / elapsed
 
     if rank == 0:
@@ -233,7 +247,7 @@ def main():
         th = time.perf_counter()
         for _ in range(3):
             eng.synthesize(ids_h, lens_h, spk_h, out_pcm=pcm_h)
-        host_rate = B * T * hop * 3 / (time.perf_counter() - th)
+        host_rate = valid_frames * hop * 3 / (time.perf_counter() - th)
         log(f"[bench] host-inclusive (pageable ids in, PCM out over PCIe): {host_rate:,.0f} samples/s per GPU")
         out = {
             "metric": "audio samples/sec (22.05 kHz, batch-32 per GPU, FastSpeech2 + HiFi-GAN inference)",
@@ -241,9 +255,10 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f32 (acoustic model) + bf16x3 split-precision (vocoder)",
             "data": "synthetic",
-            "config": {"workload": f"B={B}/GPU fixed-length L={L} phonemes x {FRAMES_PER_PHONEME} frames = T={T} frames "
-                                   f"({T * hop} samples, {T * hop / dims.sample_rate:.2f} s) per utterance; default model_config "
-                                   "(6+6 FFT blocks H=384, HiFi-GAN V1), random-init weights",
+            "config": {"workload": (f"B={B}/GPU fixed-length L={L} phonemes x {FRAMES_PER_PHONEME} frames = T={T} frames "
+                                    f"({T * hop} samples, {T * hop / dims.sample_rate:.2f} s) per utterance" if args.workload == "fixed" else
+                                    f"B={B}/GPU mixed lengths 40..200 phonemes padded to L={L} (T={T}), {valid_frames} valid frames")
+                                   + "; default model_config (6+6 FFT blocks H=384, HiFi-GAN V1), random-init weights",
                        "sample_rate": dims.sample_rate, "global_batch": world * B, "parallelism": f"utterance-sharded x{world}"},
             "real_time_factor": value / dims.sample_rate,
             "host_inclusive_samples_per_s_per_gpu": host_rate,

@@ -113,9 +113,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 
   const int b = blockIdx.z;
   const int n0 = blockIdx.y * BN;
-  const int mtiles = (p.T + BM - 1) / BM;
+  // ragged batches: rows >= act_rows[b] are not needed by anyone (see engine.hip) -- whole tiles beyond them are skipped
+  const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
+  const int mtiles = (t_act + BM - 1) / BM;
   const int tile0 = blockIdx.x * tiles_per_block;
   const int ntile = min(tiles_per_block, mtiles - tile0);
+  if (ntile <= 0) return;  // uniform for the workgroup, before any barrier
   const float* in_b = p.in + (long long)b * p.in_bs;
   const int nchunk = (p.Cin + BK - 1) / BK;
   const int KC = X3 ? p.KW * nchunk * BK : p.KW * p.Cin;  // X3 weights: [Cout][KW][nchunk][32 words], chunk-padded

@@ -101,6 +101,8 @@ struct e2etts_engine {
   int st_B = 0, st_carry_n = 0, st_halo = 0, st_emit_n = 0, st_emit_off = 0, st_win_n = 0;
   long long st_emitted = 0;
   bool st_open = false, st_done = false;
+  int ragged = 1;         // synthesize(): skip rows of shorter utterances that no valid output sample depends on
+  DevBuf actbuf;          // [2 + voc_stages + 1][B] int32 row limits
   int dec_precision = 1;  // same choice for decoder + mel_linear + postnet (encoder / variance adaptor: always fp32)
 
   // profiling
@@ -150,6 +152,8 @@ int ensure(e2etts_engine* e, DevBuf& b, size_t bytes) {
   }
   b.cap = want;
   e->dev_bytes += want;
+  // ragged mode leaves rows nobody needs uncomputed: make sure what they hold is at least finite
+  HIPCHK(e, hipMemsetAsync(b.p, 0, want, e->stream));
   return E2ETTS_OK;
 }
 
@@ -377,8 +381,25 @@ int bind_vocoder(e2etts_engine* e) {
   return E2ETTS_OK;
 }
 
+// Frames of mel context one output frame depends on, each side (conservative bound from the layer geometry: conv_post 3
+// samples, per stage the widest ResBlock1 sum_m ((k-1)/2 d_m + (k-1)/2), each upsampler +-2 input positions, conv_pre 3 frames).
+int vocoder_halo_frames(const e2etts_config& c) {
+  double r = 3.0;
+  for (int i = c.voc_stages - 1; i >= 0; --i) {
+    int worst = 0;
+    for (int j = 0; j < c.voc_n_kernels; ++j) {
+      int sum = 0;
+      for (int m = 0; m < c.voc_n_dil; ++m) sum += (c.voc_rb_kernel[j] - 1) / 2 * (c.voc_rb_dil[j][m] + 1);
+      worst = std::max(worst, sum);
+    }
+    r = (r + worst) / c.voc_up_rate[i] + 2.0;
+  }
+  return (int)std::ceil(r + 3.0);
+}
+
 // 6 x FFTBlock (reference U/blocks/transformer.py:178-189), in place on x ([B, N, H]); lens32: device [B]
-int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3) {
+int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3,
+              const int32_t* act = nullptr) {
   const auto& c = e->cfg;
   const int H = c.hidden, F = c.ffn_dim;
   float* qkv = ptr<float>(e->qkv);
@@ -387,7 +408,7 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
   float* hid = ptr<float>(e->hid);
   for (const FFTLayer& f : layers) {
     ConvParams p;
-    p.B = B; p.T = N;
+    p.B = B; p.T = N; p.act_rows = act;
     // q | k | v projections as one GEMM (U/blocks/transformer.py:220-222)
     const bool sx = x3 && f.wqkv_x3;
     p.in = x; p.w = sx ? f.wqkv_x3 : f.wqkv; p.x3 = sx; p.bias = f.bqkv; p.out = qkv; p.Cin = H; p.Cout = 3 * H;
@@ -398,7 +419,7 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
       KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, e->stream));
     }
     // fc + residual (:238-239), LayerNorm eps 1e-5, masked_fill (:182-183)
-    p = ConvParams(); p.B = B; p.T = N;
+    p = ConvParams(); p.B = B; p.T = N; p.act_rows = act;
     p.in = att; p.w = sx ? f.wo_x3 : f.wo; p.x3 = sx; p.bias = f.bo; p.res = x; p.out = tmp; p.Cin = H; p.Cout = H;
     RET(conv(e, p));
     {
@@ -406,11 +427,11 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
       KCHK(e, launch_layernorm(tmp, xalt, f.ln1g, f.ln1b, lens, B, N, H, 1e-5f, e->stream));
     }
     // conv k9 + ReLU, conv k1 + residual, LayerNorm, masked_fill (:289-297, :185-187)
-    p = ConvParams(); p.B = B; p.T = N;
+    p = ConvParams(); p.B = B; p.T = N; p.act_rows = act;
     p.in = xalt; p.w = sx ? f.w1_x3 : f.w1; p.x3 = sx; p.bias = f.b1; p.out = hid; p.Cin = H; p.Cout = F; p.KW = c.ffn_k1; p.pad = (c.ffn_k1 - 1) / 2;
     p.act = ACT_RELU;
     RET(conv(e, p));
-    p = ConvParams(); p.B = B; p.T = N;
+    p = ConvParams(); p.B = B; p.T = N; p.act_rows = act;
     p.in = hid; p.w = sx ? f.w2_x3 : f.w2; p.x3 = sx; p.bias = f.b2; p.res = xalt; p.out = tmp; p.Cin = F; p.Cout = H;
     RET(conv(e, p));
     {
@@ -476,7 +497,7 @@ __global__ void lens_to_i32_kernel(const int64_t* in, int32_t* out, int B, int L
 }
 
 int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int B, int L, const int64_t* speaker,
-                  int n_spk_ids, float d_control, float p_control, float e_control) {
+                  int n_spk_ids, float d_control, float p_control, float e_control, bool ragged = false) {
   const auto& c = e->cfg;
   if (!e->ac_loaded) return e->fail(E2ETTS_ESTATE, "acoustic weights not loaded");
   if (!ids || !lens || !speaker) return e->fail(E2ETTS_EINVAL, "ids / lens / speaker must not be NULL");
@@ -608,7 +629,21 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_length_regulate(xs, ptr<int32_t>(e->cum), ml, dpos, dx, B, L, (int)T, H, e->stream));
   }
-  RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1));
+  // Ragged mode (synthesize only).  Decoder: every consumer of a row >= mel_len masks it (keys are masked, the LayerNorm
+  // kernels write zeros there), so its convolutions compute rows < mel_len only and valid rows stay bit-identical.
+  // mel_linear / postnet are unmasked and the vocoder reads `halo` frames past the end, so they compute rows
+  // < mel_len + halo + 2 * postnet_layers; rows beyond hold stale finite values that no valid sample depends on.
+  const int32_t *act_dec = nullptr, *act_post = nullptr;
+  if (ragged) {
+    RET(ensure(e, e->actbuf, (size_t)(3 + c.voc_stages) * B * 4));
+    int32_t* ab = ptr<int32_t>(e->actbuf);
+    const int halo = vocoder_halo_frames(c);
+    KCHK(e, launch_act_rows(ml, ab, B, 0, 1, T, e->stream));
+    KCHK(e, launch_act_rows(ml, ab + B, B, halo + 2 * c.postnet_layers * ((c.postnet_kernel - 1) / 2), 1, T, e->stream));
+    act_dec = ab;
+    act_post = ab + B;
+  }
+  RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1, act_dec));
   // mel_linear (U/model.py:186)
   ConvParams p;
   auto setw = [&](ConvParams& q, const ConvW& w) {
@@ -616,7 +651,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     if (e->dec_precision == 1 && w.wx3) { q.w = w.wx3; q.x3 = 1; }
     else { q.w = w.w; q.x3 = 0; }
   };
-  p.B = B; p.T = (int)T; p.in = dx; setw(p, e->mel_lin); p.out = ptr<float>(e->mel); p.Cin = H; p.Cout = c.n_mel;
+  p.B = B; p.T = (int)T; p.act_rows = act_post; p.in = dx; setw(p, e->mel_lin); p.out = ptr<float>(e->mel); p.Cin = H; p.Cout = c.n_mel;
   RET(conv(e, p));
   // Postnet (U/layers.py:556-563; BatchNorm folded at pack time) + residual (U/model.py:188); unmasked
   const float* pin = ptr<float>(e->mel);
@@ -625,7 +660,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   for (int i = 0; i < c.postnet_layers; ++i) {
     const bool last = i == c.postnet_layers - 1;
     p = ConvParams();
-    p.B = B; p.T = (int)T; p.in = pin; setw(p, e->postnet[i]); p.Cin = cin;
+    p.B = B; p.T = (int)T; p.act_rows = act_post; p.in = pin; setw(p, e->postnet[i]); p.Cin = cin;
     p.Cout = last ? c.n_mel : c.postnet_dim; p.KW = c.postnet_kernel; p.pad = (c.postnet_kernel - 1) / 2;
     if (last) { p.out = ptr<float>(e->melpost); p.res = ptr<float>(e->mel); }
     else { p.out = bufs[i & 1]; p.act = ACT_TANH; }
@@ -639,7 +674,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
 }
 
 // HifiGan.forward (V/generator.py:37-53) on channels-last mel [B, T, n_mel] already in HBM
-int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want_wav, bool want_pcm) {
+int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want_wav, bool want_pcm, const int32_t* ragged_lens = nullptr) {
   const auto& c = e->cfg;
   if (!e->voc_loaded) return e->fail(E2ETTS_ESTATE, "vocoder weights not loaded");
   if (B <= 0 || T <= 0) return e->fail(E2ETTS_EINVAL, "B and T must be positive");
@@ -670,8 +705,22 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     if (e->voc_precision != E2ETTS_PRECISION_FP32 && w.wx3) { q.w = w.wx3; q.x3 = e->voc_precision; }
     else { q.w = w.w; q.x3 = 0; }
   };
+  // Ragged mode: utterance b needs output frames < mel_len + halo only (halo = receptive field of the whole generator in
+  // frames); each stage computes those frames at its own rate.  What lies beyond is stale but finite and out of reach.
+  const int32_t* act_stage[E2ETTS_MAX_STAGES + 1] = {nullptr};
+  if (ragged_lens) {
+    RET(ensure(e, e->actbuf, (size_t)(3 + c.voc_stages) * B * 4));
+    int32_t* ab = ptr<int32_t>(e->actbuf) + 2 * B;
+    const int halo = vocoder_halo_frames(c);
+    long long rate = 1;
+    for (int i = 0; i <= c.voc_stages; ++i) {
+      KCHK(e, launch_act_rows(ragged_lens, ab + (size_t)i * B, B, halo, (int)rate, (long long)T * rate, e->stream));
+      act_stage[i] = ab + (size_t)i * B;
+      if (i < c.voc_stages) rate *= c.voc_up_rate[i];
+    }
+  }
   ConvParams p;
-  p.B = B; p.T = T; p.in = mel_btc; setw(p, e->voc_pre); p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
+  p.B = B; p.T = T; p.act_rows = act_stage[0]; p.in = mel_btc; setw(p, e->voc_pre); p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
   p.KW = 7; p.pad = 3;
   RET(conv(e, p));
   long long n = T;
@@ -682,7 +731,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     // leaky_relu(0.1) -> ConvTranspose1d(k = 2s, stride s, pad s/2)  (V/generator.py:40-41) as a 3-tap convolution
     // with s * co output channels: row q of the [n, s*co] result IS rows q*s .. q*s+s-1 of the [n*s, co] signal.
     p = ConvParams();
-    p.B = B; p.T = (int)n; p.in = S; setw(p, e->voc_up[i]); p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
+    p.B = B; p.T = (int)n; p.act_rows = act_stage[i]; p.in = S; setw(p, e->voc_up[i]); p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
     p.KW = 3; p.pad = 1; p.in_slope = 0.1f;
     RET(conv(e, p, 2.0 / 3.0));
     n *= s;
@@ -696,14 +745,14 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         const int d = c.voc_rb_dil[j][m];
         // xt = c1(lrelu(x)); the lrelu that feeds c2 is applied here, in c1's epilogue (V/layers.py:35-38)
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.in = cur; setw(p, e->rb_c1[idx][m]); p.out = T1; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.in = cur; setw(p, e->rb_c1[idx][m]); p.out = T1; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = d; p.pad = (k * d - d) / 2; p.in_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f;
         RET(conv(e, p));
         // x = c2(xt) + x (:38-39); the last pair adds into the stage sum, and the last ResBlock divides by num_kernels
         // (V/generator.py:44-48)
         const bool last = m == c.voc_n_dil - 1;
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.in = T1; setw(p, e->rb_c2[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.in = T1; setw(p, e->rb_c2[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = 1; p.pad = (k - 1) / 2;
         if (last) {
           p.out = S;
@@ -778,7 +827,7 @@ void e2etts_destroy(e2etts_engine* e) {
   DevBuf* bufs[] = {&e->blob, &e->ids, &e->lens64, &e->lens32, &e->spk, &e->xa, &e->xb, &e->xs, &e->xp, &e->tmp, &e->qkv, &e->att,
                     &e->hid, &e->p1, &e->p2, &e->logd, &e->durf, &e->cum, &e->mel64, &e->mel32, &e->posbuf, &e->ppred, &e->epred,
                     &e->pidx, &e->eidx, &e->dx, &e->dxb, &e->mel, &e->melpost, &e->pn1, &e->pn2, &e->encout, &e->melin, &e->v0,
-                    &e->v1, &e->v2, &e->v3, &e->wav, &e->pcm, &e->st_carry, &e->st_win};
+                    &e->v1, &e->v2, &e->v3, &e->wav, &e->pcm, &e->st_carry, &e->st_win, &e->actbuf};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
@@ -919,9 +968,10 @@ int e2etts_synthesize(e2etts_engine* e, const int64_t* ids, const int64_t* lens,
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(e, hipSetDevice(e->device));
   if (B > 4096) return e->fail(E2ETTS_EINVAL, "B > 4096");
-  RET(acoustic_impl(e, ids, lens, B, L, speaker, n_spk_ids, d_control, p_control, e_control));
+  const bool ragged = e->ragged != 0;
+  RET(acoustic_impl(e, ids, lens, B, L, speaker, n_spk_ids, d_control, p_control, e_control, ragged));
   if (T_out) *T_out = e->last_T;
-  RET(vocoder_impl(e, ptr<float>(e->melpost), B, e->last_T, false, true));
+  RET(vocoder_impl(e, ptr<float>(e->melpost), B, e->last_T, false, true, ragged ? ptr<int32_t>(e->mel32) : nullptr));
   if (mel_lens_out) RET(copy_out(e, mel_lens_out, e->mel64.p, (size_t)B * 8));
   const size_t ns = (size_t)B * e->last_T * e->cfg.hop_length;
   if (pcm_out) {
@@ -957,22 +1007,6 @@ int e2etts_fetch_wav(e2etts_engine* e, float* wav_out, size_t capacity) {
   RET(copy_out(e, wav_out, e->wav.p, ns * 4));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return E2ETTS_OK;
-}
-
-// Frames of mel context one output frame depends on, each side (conservative bound from the layer geometry: conv_post 3
-// samples, per stage the widest ResBlock1 sum_m ((k-1)/2 d_m + (k-1)/2), each upsampler +-2 input positions, conv_pre 3 frames).
-static int vocoder_halo_frames(const e2etts_config& c) {
-  double r = 3.0;
-  for (int i = c.voc_stages - 1; i >= 0; --i) {
-    int worst = 0;
-    for (int j = 0; j < c.voc_n_kernels; ++j) {
-      int sum = 0;
-      for (int m = 0; m < c.voc_n_dil; ++m) sum += (c.voc_rb_kernel[j] - 1) / 2 * (c.voc_rb_dil[j][m] + 1);
-      worst = std::max(worst, sum);
-    }
-    r = (r + worst) / c.voc_up_rate[i] + 2.0;
-  }
-  return (int)std::ceil(r + 3.0);
 }
 
 int e2etts_vocoder_stream_begin(e2etts_engine* e, int B) {
@@ -1060,6 +1094,13 @@ int e2etts_set_precision(e2etts_engine* e, int vocoder_precision, int decoder_pr
     return e->fail(E2ETTS_EINVAL, "decoder precision must be fp32 or bf16x3 (got %d)", decoder_precision);
   e->voc_precision = vocoder_precision;
   e->dec_precision = decoder_precision;
+  return E2ETTS_OK;
+}
+
+int e2etts_set_ragged(e2etts_engine* e, int enable) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->ragged = enable != 0;
   return E2ETTS_OK;
 }
 

@@ -20,6 +20,7 @@ struct ConvParams {
   const float* res = nullptr;    // optional residual, same indexing as out
   float* out = nullptr;          // [B, T, Cout]
   const int32_t* lens = nullptr; // optional [B]: output rows t >= lens[b] are written as 0
+  const int32_t* act_rows = nullptr; // optional [B]: only output rows < act_rows[b] are computed at all (ragged batches)
   int B = 0, T = 0, Cin = 0, Cout = 0, KW = 1, dil = 1, pad = 0;
   long long in_bs = 0, out_bs = 0, res_bs = 0;
   int in_ld = 0, out_ld = 0, res_ld = 0;
@@ -69,6 +70,8 @@ const char* launch_variance_embed(float* x, float* pitch_pred /*[B,L,2], scaled 
 // length regulator fused with the decoder position add: y[b, t, :] = (t < mel_len[b] ? x[b, ph(t), :] : 0) + pos[t, :]
 const char* launch_length_regulate(const float* x, const int32_t* cum, const int32_t* mel_lens, const float* pos,
                                    float* y, int B, int L, int T, int H, hipStream_t s);
+// out[b] = min(cap, (lens[b] + add) * mul): rows a layer has to compute for utterance b in ragged mode
+const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s);
 // [B, C, T] -> [B, T, C]
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s);
 // wav = tanh(conv7(lrelu_0.01(x))) with Cout = 1; pcm = (int16)(int32)(wav * 32768)

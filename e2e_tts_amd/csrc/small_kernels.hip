@@ -262,6 +262,15 @@ __global__ __launch_bounds__(128) void length_regulate_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------- ragged-batch row limits
+__global__ void act_rows_kernel(const int32_t* __restrict__ lens, int32_t* __restrict__ out, int B, int add, int mul, long long cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) {
+    const long long v = ((long long)lens[i] + add) * mul;
+    out[i] = (int32_t)(v < cap ? v : cap);
+  }
+}
+
 // ---------------------------------------------------------------- [B, C, T] -> [B, T, C]
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T) {
   __shared__ float tile[32][33];
@@ -403,6 +412,12 @@ const char* launch_length_regulate(const float* x, const int32_t* cum, const int
   if (T <= 0 || H % 4) return "length_regulate: bad dims";
   hipLaunchKernelGGL(length_regulate_kernel, dim3(T, B), dim3(128), 0, s, x, cum, mel_lens, pos, y, L, T, H);
   return CHECK_LAUNCH("length_regulate");
+}
+
+const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s) {
+  if (!lens || !out || B <= 0) return "act_rows: bad arguments";
+  hipLaunchKernelGGL(act_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lens, out, B, add, mul, cap);
+  return CHECK_LAUNCH("act_rows");
 }
 
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s) {

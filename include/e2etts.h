@@ -144,6 +144,13 @@ int e2etts_vocoder_stream_fetch(e2etts_engine* engine, float* wav_out, int16_t* 
                                    BASELINE config 5 (long-form streaming) names; waveform error ~5e-4, above the fp32 bar */
 int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decoder_precision);
 
+/* Ragged batches (default on).  e2etts_synthesize hands back, per utterance, only mel_lens[b] * hop valid samples; with
+ * ragged != 0 it therefore skips, layer by layer, the rows of shorter utterances that no valid sample depends on (rows past
+ * mel_len + receptive-field halo), instead of computing the whole padded batch as the reference does.  Valid samples are
+ * bit-identical either way; what lies beyond them in the padded PCM rows is then unspecified.  e2etts_acoustic /
+ * e2etts_vocoder always compute the full padded tensors (their padded rows match the reference's). */
+int e2etts_set_ragged(e2etts_engine* engine, int enable);
+
 /* Per-kernel-class timing with HIP events on the engine's stream (bench.py roofline leg).
  * enable != 0 starts recording (and clears counters); e2etts_profile_read fills up to `cap` records. */
 typedef struct e2etts_kernel_stat {

@@ -34,6 +34,9 @@ PHONEMES = 128
 FRAMES_PER_PHONEME = 6
 
 
+CONV_CLASSES = ("conv_gemm", "conv_x3", "x3 ", "f32 ")  # the last two: per-layer classes under E2ETTS_PROFILE_FINE=1
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -215,8 +218,8 @@ def main():
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                     "launches_per_step": dom["launches"] / args.steps,
-                    "all_conv_gemm_tflops": round(sum(s["flops"] for s in stats_k if s["name"].startswith("conv_gemm")) /
-                                                  (sum(s["ms"] for s in stats_k if s["name"].startswith("conv_gemm")) * 1e-3) / 1e12, 3),
+                    "all_conv_tflops": round(sum(s["flops"] for s in stats_k if s["name"].startswith(CONV_CLASSES)) /
+                                             max(sum(s["ms"] for s in stats_k if s["name"].startswith(CONV_CLASSES)) * 1e-3, 1e-9) / 1e12, 3),
                     "kernel_ms_per_step": round(kernel_ms, 3)}
         # the same hot path with every convolution on the exact-fp32 MFMA (e2etts_set_precision fp32): reported beside the
         # default split-precision run so that both kernels' roofline fractions are on record

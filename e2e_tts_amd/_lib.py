@@ -266,10 +266,10 @@ class Engine:
         self._check(self.lib.e2etts_profile_enable(self._h, 1 if on else 0), "e2etts_profile_enable")
 
     def profile_read(self):
-        arr = (KernelStat * 64)()
-        n = self._check(self.lib.e2etts_profile_read(self._h, arr, 64), "e2etts_profile_read")
+        arr = (KernelStat * 256)()
+        n = self._check(self.lib.e2etts_profile_read(self._h, arr, 256), "e2etts_profile_read")
         return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms), flops=float(arr[i].flops),
-                     bytes=float(arr[i].bytes)) for i in range(min(n, 64))]
+                     bytes=float(arr[i].bytes)) for i in range(min(n, 256))]
 
     def device_bytes(self) -> int:
         return int(self.lib.e2etts_device_bytes(self._h))

@@ -87,7 +87,13 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
 //             bytes as the fp32 row; activations are split while staging, weights arrive pre-split from the packer.
 // MODE 0: exact fp32; 1: bf16x3 split precision; 2: plain bf16 (hi x hi only).  A compile-time mode keeps the MFMA block one
 // straight basic block (a runtime flag put a branch between every few MFMAs).
-template <int BM, int BN, int WM, int WN, int MODE>
+// ACCUM: the epilogue adds what the output rows hold already (requested early, next to the residual rows); a kernel
+// parameter of its own so that the launches without it keep their register budget (3 waves / SIMD at 32 channels).
+// VEC:   float4 epilogue (channel counts and strides multiples of 4, 16-byte aligned pointers -- every launch of the
+//        engine).  The scalar epilogue for odd shapes lives in instantiations of its own: next to the vector one, its
+//        conditional loads made hipcc drain vmcnt(0) after every barrier of the main loop, i.e. wait for the weight
+//        tile it had just requested before issuing the first MFMA.
+template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
   constexpr bool X3 = MODE != 0;
   constexpr bool SPLIT = MODE == 1;
@@ -233,9 +239,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   // residual tile is fetched up front with unconditional (clamped) loads, NONE / ReLU / leaky-ReLU are one
   // max(v, v * slope), and only the stores are predicated -- straight-line code lets hipcc count its vmcnt waits instead
   // of draining every load and store one at a time (which cost ~16k cycles per tile).
-  const bool vec_ok = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && ((p.out_bs & 3) == 0) && (((uintptr_t)p.out & 15) == 0) &&
-                      (!p.res || ((p.res_ld % 4 == 0) && ((p.res_bs & 3) == 0) && (((uintptr_t)p.res & 15) == 0))) &&
-                      (!p.bias || (((uintptr_t)p.bias & 15) == 0));
   const int len = p.lens ? p.lens[b] : p.T;
   float* out_b = p.out + (long long)b * p.out_bs;
   const float* res_b = p.res ? p.res + (long long)b * p.res_bs : nullptr;
@@ -247,11 +250,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   const bool ecol_ok = ecol < p.Cout;
   const int ecol_c = min(ecol, max(p.Cout - 4, 0));
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (vec_ok && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + ecol_c);
+  if (VEC && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + ecol_c);
   const float eslope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LRELU ? p.act_slope : 1.f);
 
   auto epilogue_vec = [&](int tile, auto has_res) {
     constexpr bool RES = decltype(has_res)::value;
+    constexpr bool ACC = ACCUM;
     const int t0 = tile * BM + wm * WM;
     float* patch = As + wave * (16 * ELD);  // wave-private: no workgroup barrier between its write and read
 #pragma unroll
@@ -264,6 +268,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
           for (int ps = 0; ps < PASSES; ++ps) {
             const int t = min(t0 + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
             resv[hh][ps] = *reinterpret_cast<const float4*>(res_b + (long long)t * p.res_ld + ecol_c);
+          }
+      }
+      float4 accv[2][PASSES];  // accumulate mode: what the output rows hold now, requested together with the residual
+      if constexpr (ACC) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) {
+            const int t = min(t0 + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
+            accv[hh][ps] = *reinterpret_cast<const float4*>(out_b + (long long)t * p.out_ld + ecol_c);
           }
       }
 #pragma unroll
@@ -292,11 +306,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
           if (t >= len) v = make_float4(0.f, 0.f, 0.f, 0.f);
           const bool ok = t < p.T && ecol_ok;
           float4* o = reinterpret_cast<float4*>(out_b + (long long)min(t, p.T - 1) * p.out_ld + ecol_c);
-          if (p.accumulate) {
-            const float4 ov = *o;
+          if constexpr (ACC) {
+            const float4 ov = accv[hh][ps];
             v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
           }
-          if (p.out_div != 1.0f) {
+          if (ACC && p.out_div != 1.0f) {
             v.x = v.x / p.out_div; v.y = v.y / p.out_div; v.z = v.z / p.out_div; v.w = v.w / p.out_div;
           }
           if (ok) *o = v;
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
     }
   };
   auto epilogue = [&](int tile) {
-    if (vec_ok) {
+    if constexpr (VEC) {
       if (res_b) epilogue_vec(tile, std::true_type{});
       else epilogue_vec(tile, std::false_type{});
     } else {
@@ -447,8 +461,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
-const char* launch_cfg(const ConvParams& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC>
+const char* launch_cfg_acc(const ConvParams& p, hipStream_t s) {
   const int halo = p.dil * (p.KW - 1);
   const size_t lds = (size_t)((BM + halo) * LDK + 2 * BN * LDK) * sizeof(float);
   if (lds > 64 * 1024) return "conv_gemm: LDS tile exceeds 64 KiB";
@@ -460,8 +474,19 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
   tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
   if (tpb > mtiles) tpb = mtiles;
   dim3 grid((mtiles + tpb - 1) / tpb, ntiles, p.B);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE>), grid, dim3(256), lds, s, p, tpb);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC>), grid, dim3(256), lds, s, p, tpb);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+const char* launch_cfg(const ConvParams& p, hipStream_t s) {
+  return p.accumulate ? launch_cfg_acc<BM, BN, WM, WN, MODE, true, true>(p, s) : launch_cfg_acc<BM, BN, WM, WN, MODE, false, true>(p, s);
+}
+
+bool epilogue_vec_ok(const ConvParams& p) {
+  return (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && ((p.out_bs & 3) == 0) && (((uintptr_t)p.out & 15) == 0) &&
+         (!p.res || ((p.res_ld % 4 == 0) && ((p.res_bs & 3) == 0) && (((uintptr_t)p.res & 15) == 0))) &&
+         (!p.bias || (((uintptr_t)p.bias & 15) == 0));
 }
 
 }  // namespace
@@ -487,10 +512,16 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   if (p.in_ld < p.Cin || p.out_ld < p.Cout || (p.res && p.res_ld < p.Cout)) return "conv_gemm: row stride < channels";
   if (p.dil * (p.KW - 1) > MAX_HALO) return "conv_gemm: dilation * (KW - 1) exceeds the slab halo limit";
   if (p.pad < 0 || p.pad > p.dil * (p.KW - 1)) return "conv_gemm: pad out of range";
+  if (p.out_div != 1.0f && !p.accumulate) return "conv_gemm: out_div needs accumulate (it closes a sum of branches)";
   if (p.x3 < 0 || p.x3 > 2) return "conv_gemm: x3 must be 0 (fp32), 1 (bf16x3) or 2 (bf16)";
   if (p.in_slope < 0.f || p.in_slope > 1.f) return "conv_gemm: in_slope must lie in [0, 1]";
   if ((long long)p.T * p.in_ld * 4 >= (1LL << 31) || (long long)p.Cout * p.KW * ((p.Cin + 31) / 32 * 32) * 4 >= (1LL << 31))
     return "conv_gemm: one utterance / the weight matrix must stay below 2 GiB (32-bit buffer offsets)";
+  if (!epilogue_vec_ok(p)) {  // odd channel counts / strides: one tile shape per arithmetic mode, scalar epilogue
+    if (p.x3 == 1) return launch_cfg_acc<128, 128, 64, 64, 1, false, false>(p, s);
+    if (p.x3 == 2) return launch_cfg_acc<128, 128, 64, 64, 2, false, false>(p, s);
+    return launch_cfg_acc<128, 128, 64, 64, 0, false, false>(p, s);
+  }
   if (p.x3 == 1) {
     if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 1>(p, s);
     if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 1>(p, s);

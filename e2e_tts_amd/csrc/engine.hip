@@ -239,7 +239,13 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
   if (p.in_bs == 0) p.in_bs = (long long)p.T * p.in_ld;
   if (p.out_bs == 0) p.out_bs = (long long)p.T * p.out_ld;
   if (p.res && p.res_bs == 0) p.res_bs = (long long)p.T * p.res_ld;
-  ProfScope ps(e, conv_cfg_name(p.Cout, p.x3), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
+  // E2ETTS_PROFILE_FINE=1: one profile class per layer shape instead of per kernel configuration (a tuning aid)
+  static const bool fine = getenv("E2ETTS_PROFILE_FINE") != nullptr;
+  char fname[48];
+  if (fine && e->prof_on)
+    snprintf(fname, sizeof fname, "%s %d>%d k%d d%d r%lld%s%s", p.x3 ? "x3" : "f32", p.Cin, p.Cout, p.KW, p.dil,
+             (long long)p.B * p.T, p.res ? "+r" : "", p.accumulate ? "+a" : "");
+  ProfScope ps(e, fine && e->prof_on ? fname : conv_cfg_name(p.Cout, p.x3), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
   KCHK(e, launch_conv_gemm(p, e->stream));
   return E2ETTS_OK;
 }

@@ -93,8 +93,9 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
 //        engine).  The scalar epilogue for odd shapes lives in instantiations of its own: next to the vector one, its
 //        conditional loads made hipcc drain vmcnt(0) after every barrier of the main loop, i.e. wait for the weight
 //        tile it had just requested before issuing the first MFMA.
-template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC>
+template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
+  static_assert(!BFRAG || MODE != 0, "fragment-order weights exist for the bf16 modes only");
   constexpr bool X3 = MODE != 0;
   constexpr bool SPLIT = MODE == 1;
   constexpr int NWN = BN / WN;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   float* Bs = smem + arows * LDK;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
   const int wm = wave / NWN, wn = wave % NWN;
   const int li = lane & 31, lh = lane >> 5;
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
@@ -151,6 +152,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((long long)p.Cout * KC * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t in_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((long long)p.T * p.in_ld * 4), 0x00020000);
+  // BFRAG: weights in fragment order [n_tile32][tap][chunk][k-step][hi|lo][lane][8 bf16]: one fully coalesced 1 KiB
+  // buffer_load_dwordx4 per fragment, per wave, served by L2 (the tensor is <= a few MB and shared by every workgroup).
+  // No LDS tile, no ds_write pass and -- the point -- no workgroup barrier per tap: barriers remain per slab only.
+  const int ntile32 = (p.Cout + 31) / 32;
+  const __amdgpu_buffer_rsrc_t wf_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(BFRAG ? p.wfrag : p.w), 0, BFRAG ? (int)((long long)ntile32 * p.KW * nchunk * 4096) : 16, 0x00020000);
+  int fnt[NT];  // this wave's 32-column tiles (clamped: columns beyond Cout are never stored)
+#pragma unroll
+  for (int n = 0; n < NT; ++n) fnt[n] = min((n0 + wn * WN) / 32 + n, ntile32 - 1);
+  float4 bfr[BK / 16][NT][2];  // [k-step][n tile][hi | lo] fragments of the CURRENT iteration (BFRAG)
+  auto load_frag = [&](int chunk, int j, int ks) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        const int soff = ((((fnt[n] * p.KW + j) * nchunk + chunk) * (BK / 16) + ks) * 2 + hl) * 1024;
+        bfr[ks][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
+      }
+  };
   int wvoff[BROWS];
   bool wok[BROWS];
   bool w_all_ok = true;
@@ -352,13 +372,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    // gfx9 counts loads and stores in one vmcnt; with stores possibly in flight hipcc turns every counted wait of the
+    // main loop into vmcnt(0).  Draining once per tile keeps the per-tap waits for the weight fragments counted.
+    if constexpr (BFRAG) __builtin_amdgcn_s_waitcnt(0x0F70);
   };
 
   __builtin_amdgcn_s_setprio(3);
   load_a(tile0, 0);
   store_a();
-  load_b(0, 0);
-  store_b(0);
+  if constexpr (BFRAG) {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) load_frag(0, 0, ks);
+    // hipcc may issue these in any order; whatever is still in flight at the loop head would force the head's wait for
+    // the first fragment down to vmcnt(0) in EVERY iteration.  Drained here, the wait inside the loop stays counted.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  } else {
+    load_b(0, 0);
+    store_b(0);
+  }
   int cur = 0;
   int tl = 0, chunk = 0, j = 0;  // work item = (tile0 + tl, chunk); tap j
 #ifdef E2ETTS_DIAG
@@ -372,13 +403,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
     const int nchk = chunk + 1 == nchunk ? 0 : chunk + 1;
     // Weight tile first, slab second: hipcc reuses the registers of earlier loads for address arithmetic and then
     // waits (vmcnt) for whatever is in flight -- with the slab loads issued first that was a full HBM round trip.
-    if (it + 1 < niter) {  // next weight tile: next tap, or tap 0 of the next item's chunk
-      if (!last_tap) load_b(chunk, j + 1);
-      else load_b(nchk, 0);
+    if constexpr (!BFRAG) {
+      if (it + 1 < niter) {  // next weight tile: next tap, or tap 0 of the next item's chunk
+        if (!last_tap) load_b(chunk, j + 1);
+        else load_b(nchk, 0);
+      }
     }
     if (last_tap && more_items) load_a(tile0 + tl + (nchk == 0 ? 1 : 0), nchk);  // next slab: next chunk, or next tile
     DIAG_STAMP(tb); DIAG_ADD(0, ta, tb);
-    __syncthreads();  // slab + Bs[cur] visible
+    if (!BFRAG || j == 0) __syncthreads();  // slab (+ Bs[cur]) visible; with BFRAG only a new slab needs the barrier
     DIAG_STAMP(ta); DIAG_ADD(1, tb, ta);
 
     // Between two waves of a SIMD the one streaming MFMAs starves the other's vector issue (measured: ~1 MFMA
@@ -398,8 +431,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          bh[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + ks * 8));
-          bl[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + 16 + ks * 8));
+          if constexpr (BFRAG) {
+            bh[n] = __builtin_bit_cast(bf16x8, bfr[ks][n][0]);
+            bl[n] = __builtin_bit_cast(bf16x8, bfr[ks][n][1]);
+          } else {
+            bh[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + ks * 8));
+            bl[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + 16 + ks * 8));
+          }
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -411,6 +449,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
             }
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
           }
+        if constexpr (BFRAG) {  // fragments of this k-step are consumed: request them for the next iteration (one k-step of cover)
+          // unconditional (the very last iteration re-requests fragments nobody uses): with a branch around them
+          // hipcc has to assume "first k-step requested, second not" and waits for all eight loads at the loop head
+          if (!last_tap) load_frag(chunk, j + 1, ks);
+          else load_frag(nchk, 0, ks);
+        }
       }
     } else {
 #pragma unroll
@@ -433,7 +477,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
     }
     __builtin_amdgcn_s_setprio(3);
     DIAG_STAMP(tb); DIAG_ADD(2, ta, tb);
-    if (it + 1 < niter) store_b(cur ^ 1);  // that buffer was last read before this iteration's barrier
+    if constexpr (!BFRAG) {
+      if (it + 1 < niter) store_b(cur ^ 1);  // that buffer was last read before this iteration's barrier
+    }
     cur ^= 1;
     DIAG_STAMP(ta); DIAG_ADD(3, tb, ta);
     if (last_tap) {
@@ -461,8 +507,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC>
-const char* launch_cfg_acc(const ConvParams& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG>
+const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   const int halo = p.dil * (p.KW - 1);
   const size_t lds = (size_t)((BM + halo) * LDK + 2 * BN * LDK) * sizeof(float);
   if (lds > 64 * 1024) return "conv_gemm: LDS tile exceeds 64 KiB";
@@ -474,13 +520,21 @@ const char* launch_cfg_acc(const ConvParams& p, hipStream_t s) {
   tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
   if (tpb > mtiles) tpb = mtiles;
   dim3 grid((mtiles + tpb - 1) / tpb, ntiles, p.B);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC>), grid, dim3(256), lds, s, p, tpb);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG>), grid, dim3(256), lds, s, p, tpb);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
 }
 
+// Fragment-order weights (ConvParams::wfrag) only for the 128-column tile: +7..13 % there (A/B in tools/conv_bench), nothing
+// at 64 and 32 columns, where the weight tile is small next to the slab.
 template <int BM, int BN, int WM, int WN, int MODE>
 const char* launch_cfg(const ConvParams& p, hipStream_t s) {
-  return p.accumulate ? launch_cfg_acc<BM, BN, WM, WN, MODE, true, true>(p, s) : launch_cfg_acc<BM, BN, WM, WN, MODE, false, true>(p, s);
+  if constexpr (MODE != 0 && BN == 128) {
+    if (p.wfrag)
+      return p.accumulate ? launch_cfg_impl<BM, BN, WM, WN, MODE, true, true, true>(p, s)
+                          : launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, true>(p, s);
+  }
+  return p.accumulate ? launch_cfg_impl<BM, BN, WM, WN, MODE, true, true, false>(p, s)
+                      : launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, false>(p, s);
 }
 
 bool epilogue_vec_ok(const ConvParams& p) {
@@ -518,9 +572,9 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   if ((long long)p.T * p.in_ld * 4 >= (1LL << 31) || (long long)p.Cout * p.KW * ((p.Cin + 31) / 32 * 32) * 4 >= (1LL << 31))
     return "conv_gemm: one utterance / the weight matrix must stay below 2 GiB (32-bit buffer offsets)";
   if (!epilogue_vec_ok(p)) {  // odd channel counts / strides: one tile shape per arithmetic mode, scalar epilogue
-    if (p.x3 == 1) return launch_cfg_acc<128, 128, 64, 64, 1, false, false>(p, s);
-    if (p.x3 == 2) return launch_cfg_acc<128, 128, 64, 64, 2, false, false>(p, s);
-    return launch_cfg_acc<128, 128, 64, 64, 0, false, false>(p, s);
+    if (p.x3 == 1) return launch_cfg_impl<128, 128, 64, 64, 1, false, false, false>(p, s);
+    if (p.x3 == 2) return launch_cfg_impl<128, 128, 64, 64, 2, false, false, false>(p, s);
+    return launch_cfg_impl<128, 128, 64, 64, 0, false, false, false>(p, s);
   }
   if (p.x3 == 1) {
     if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 1>(p, s);

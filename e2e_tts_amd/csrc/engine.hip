@@ -77,6 +77,10 @@ struct e2etts_engine {
   // weights
   DevBuf blob;
   std::map<std::string, std::pair<const float*, uint64_t>> tensors;
+  // split-precision image -> the same weights in MFMA-fragment order (built on the device at load time for the layers
+  // the 128-column kernel serves: their waves read weight fragments straight from L2, no LDS tile, no barrier per tap)
+  std::map<const float*, float*> frag_of;
+  size_t frag_bytes = 0;
   bool ac_loaded = false, voc_loaded = false;
   std::vector<FFTLayer> enc, dec;
   Predictor dur, pitch, energy;
@@ -239,6 +243,10 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
   if (p.in_bs == 0) p.in_bs = (long long)p.T * p.in_ld;
   if (p.out_bs == 0) p.out_bs = (long long)p.T * p.out_ld;
   if (p.res && p.res_bs == 0) p.res_bs = (long long)p.T * p.res_ld;
+  if (p.x3 && !p.wfrag) {
+    auto it = e->frag_of.find(p.w);
+    if (it != e->frag_of.end()) p.wfrag = it->second;
+  }
   // E2ETTS_PROFILE_FINE=1: one profile class per layer shape instead of per kernel configuration (a tuning aid)
   static const bool fine = getenv("E2ETTS_PROFILE_FINE") != nullptr;
   char fname[48];
@@ -247,6 +255,27 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
              (long long)p.B * p.T, p.res ? "+r" : "", p.accumulate ? "+a" : "");
   ProfScope ps(e, fine && e->prof_on ? fname : conv_cfg_name(p.Cout, p.x3), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
   KCHK(e, launch_conv_gemm(p, e->stream));
+  return E2ETTS_OK;
+}
+
+void free_frags(e2etts_engine* e) {
+  for (auto& kv : e->frag_of) {
+    (void)hipFree(kv.second);
+  }
+  e->frag_of.clear();
+  e->dev_bytes -= e->frag_bytes;
+  e->frag_bytes = 0;
+}
+
+int make_frag(e2etts_engine* e, const float* wx3, uint64_t cout, uint64_t kw, uint64_t cin) {
+  if (!wx3 || cout <= 64 || e->frag_of.count(wx3)) return E2ETTS_OK;  // <= 64 columns: the LDS-tile kernels measured no gain
+  float* f = nullptr;
+  const size_t bytes = x3_frag_bytes((int)cout, (int)kw, (int)cin);
+  HIPCHK(e, hipMalloc(&f, bytes));
+  e->dev_bytes += bytes;
+  e->frag_bytes += bytes;
+  e->frag_of[wx3] = f;
+  KCHK(e, launch_x3_to_frag(wx3, f, (int)cout, (int)kw, (int)cin, e->stream));
   return E2ETTS_OK;
 }
 
@@ -285,6 +314,10 @@ int bind_fft(e2etts_engine* e, const char* side, int layers, std::vector<FFTLaye
       RET(get_tensor(e, p + "wo.x3", H * Hc, &f.wo_x3));
       RET(get_tensor(e, p + "w1.x3", F * c.ffn_k1 * Hc, &f.w1_x3));
       RET(get_tensor(e, p + "w2.x3", H * Fc, &f.w2_x3));
+      RET(make_frag(e, f.wqkv_x3, 3 * H, 1, H));
+      RET(make_frag(e, f.wo_x3, H, 1, H));
+      RET(make_frag(e, f.w1_x3, F, c.ffn_k1, H));
+      RET(make_frag(e, f.w2_x3, H, 1, F));
     }
   }
   return E2ETTS_OK;
@@ -337,6 +370,7 @@ int bind_acoustic(e2etts_engine* e) {
   RET(get_tensor(e, "mel.b", c.n_mel, &e->mel_lin.b));
   e->mel_lin.wx3 = nullptr;
   if (e->tensors.count("mel.w.x3")) RET(get_tensor(e, "mel.w.x3", (uint64_t)c.n_mel * ((H + 31) / 32 * 32), &e->mel_lin.wx3));
+  RET(make_frag(e, e->mel_lin.wx3, c.n_mel, 1, H));
   e->postnet.resize(c.postnet_layers);
   for (int i = 0; i < c.postnet_layers; ++i) {
     const uint64_t cin = i == 0 ? c.n_mel : c.postnet_dim, cout = i == c.postnet_layers - 1 ? c.n_mel : c.postnet_dim;
@@ -345,6 +379,7 @@ int bind_acoustic(e2etts_engine* e) {
     RET(get_tensor(e, p + "b", cout, &e->postnet[i].b));
     e->postnet[i].wx3 = nullptr;
     if (e->tensors.count(p + "w.x3")) RET(get_tensor(e, p + "w.x3", cout * c.postnet_kernel * ((cin + 31) / 32 * 32), &e->postnet[i].wx3));
+    RET(make_frag(e, e->postnet[i].wx3, cout, c.postnet_kernel, cin));
   }
   return E2ETTS_OK;
 }
@@ -355,6 +390,7 @@ int bind_conv(e2etts_engine* e, const std::string& name, uint64_t cout, uint64_t
   RET(get_tensor(e, name + ".b", cout, &w.b));
   w.wx3 = nullptr;
   if (e->tensors.count(name + ".wx3")) RET(get_tensor(e, name + ".wx3", cout * kw * ((cin + 31) / 32) * 32, &w.wx3));
+  RET(make_frag(e, w.wx3, cout, kw, cin));
   return E2ETTS_OK;
 }
 
@@ -838,6 +874,7 @@ void e2etts_destroy(e2etts_engine* e) {
     if (b->p) (void)hipFree(b->p);
   for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+  free_frags(e);
   if (e->h_mel) (void)hipHostFree(e->h_mel);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -861,6 +898,7 @@ int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
   RET(ensure(e, e->blob, nbytes));
   HIPCHK(e, hipMemcpyAsync(e->blob.p, blob, nbytes, hipMemcpyDefault, e->stream));
   e->tensors.clear();
+  free_frags(e);
   for (auto& en : dir) {
     en.name[sizeof en.name - 1] = 0;
     if ((en.offset & 255) || en.offset < h.data_offset || en.offset + en.numel * 4 > nbytes)

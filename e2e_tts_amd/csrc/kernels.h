@@ -15,6 +15,8 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3 };
 struct ConvParams {
   const float* in = nullptr;     // [B, T, Cin]  (row stride in_ld, batch stride in_bs)
   const float* w = nullptr;      // [Cout, KW*Cin] tap-major fp32; x3: [Cout, KW, ceil(Cin/32), 32 bf16 hi | 32 bf16 lo]
+  const float* wfrag = nullptr;  // x3 only, optional: the same weights in MFMA-fragment order (launch_x3_to_frag); when set,
+                                 // each wave loads its B fragments straight from global / L2 and the weight tile skips LDS
   int x3 = 0;                    // 1: split-precision bf16x3 MFMA path (w pre-split by the packer); 2: plain bf16 (hi x hi only)
   const float* bias = nullptr;   // [Cout] or null
   const float* res = nullptr;    // optional residual, same indexing as out
@@ -73,6 +75,10 @@ const char* launch_length_regulate(const float* x, const int32_t* cum, const int
 // out[b] = min(cap, (lens[b] + add) * mul): rows a layer has to compute for utterance b in ragged mode
 const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s);
 // [B, C, T] -> [B, T, C]
+// split-precision weight image -> MFMA-fragment order (ConvParams::wfrag)
+const char* launch_x3_to_frag(const float* x3, float* frag, int Cout, int KW, int Cin, hipStream_t s);
+size_t x3_frag_bytes(int Cout, int KW, int Cin);
+
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s);
 // wav = tanh(conv7(lrelu_0.01(x))) with Cout = 1; pcm = (int16)(int32)(wav * 32768)
 const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,

@@ -272,6 +272,26 @@ __global__ void act_rows_kernel(const int32_t* __restrict__ lens, int32_t* __res
 }
 
 // ---------------------------------------------------------------- [B, C, T] -> [B, T, C]
+// Split-precision weight image [Cout][KW][nchunk][32 bf16 hi | 32 bf16 lo] (packer.pack_x3) -> MFMA-fragment order
+// [ceil(Cout/32)][KW][nchunk][k-step 0..1][hi | lo][lane 0..63][8 bf16]: the 16 bytes lane l of a wave needs as B operand of
+// v_mfma_f32_32x32x16_bf16 for output column 32 t + (l & 31), k = 16 ks + 8 (l >> 5) .. + 7.  One thread moves one such
+// 16-byte group; columns >= Cout are zero.  Runs once per weight tensor at load time.
+__global__ void x3_to_frag_kernel(const uint4* __restrict__ x3, uint4* __restrict__ frag, int Cout, int KW, int nchunk, long long groups) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= groups) return;
+  const int lane = (int)(g & 63);
+  const int hl = (int)((g >> 6) & 1), ks = (int)((g >> 7) & 1);
+  long long r = g >> 8;
+  const int c = (int)(r % nchunk); r /= nchunk;
+  const int j = (int)(r % KW);
+  const int t = (int)(r / KW);
+  const int n = t * 32 + (lane & 31);
+  uint4 v = make_uint4(0, 0, 0, 0);
+  // one x3 row = 64 bf16 = 8 groups of 16 bytes: [hi k 0-7, 8-15, 16-23, 24-31 | lo ...]
+  if (n < Cout) v = x3[(((long long)n * KW + j) * nchunk + c) * 8 + hl * 4 + ks * 2 + (lane >> 5)];
+  frag[g] = v;
+}
+
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
@@ -418,6 +438,18 @@ const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, i
   if (!lens || !out || B <= 0) return "act_rows: bad arguments";
   hipLaunchKernelGGL(act_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lens, out, B, add, mul, cap);
   return CHECK_LAUNCH("act_rows");
+}
+
+size_t x3_frag_bytes(int Cout, int KW, int Cin) { return (size_t)((Cout + 31) / 32) * KW * ((Cin + 31) / 32) * 4096; }
+
+const char* launch_x3_to_frag(const float* x3, float* frag, int Cout, int KW, int Cin, hipStream_t s) {
+  if (!x3 || !frag) return "x3_to_frag: null pointer";
+  if (Cout <= 0 || KW <= 0 || Cin <= 0) return "x3_to_frag: bad dims";
+  const int nchunk = (Cin + 31) / 32;
+  const long long groups = (long long)((Cout + 31) / 32) * KW * nchunk * 256;
+  hipLaunchKernelGGL(x3_to_frag_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const uint4*>(x3), reinterpret_cast<uint4*>(frag), Cout, KW, nchunk, groups);
+  return CHECK_LAUNCH("x3_to_frag");
 }
 
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s) {

@@ -65,6 +65,21 @@ static std::vector<float> pack_x3(const std::vector<float>& w, int Cout, int KW,
   std::vector<float> r(out.size() / 2); memcpy(r.data(), out.data(), out.size() * 2); return r;
 }
 
+// fp32 [Cout][KW*Cin] -> fragment order [ntile32][KW][nchunk][ks(2)][hi|lo][lane(64)][8 bf16] (as 32-bit words)
+static std::vector<float> pack_x3_frag(const std::vector<float>& w, int Cout, int KW, int Cin) {
+  int nchunk = (Cin + 31) / 32, nt = (Cout + 31) / 32;
+  std::vector<unsigned short> out((size_t)nt * KW * nchunk * 2 * 2 * 64 * 8, 0);
+  for (int t = 0; t < nt; ++t) for (int j = 0; j < KW; ++j) for (int c = 0; c < nchunk; ++c) for (int ks = 0; ks < 2; ++ks)
+    for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
+      int n = t * 32 + (lane & 31), ch = c * 32 + ks * 16 + (lane >> 5) * 8 + e;
+      float v = (n < Cout && ch < Cin) ? w[((size_t)n * KW + j) * Cin + ch] : 0.f;
+      unsigned short hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+      size_t base = ((((size_t)(t * KW + j) * nchunk + c) * 2 + ks) * 2) * 512 + (size_t)lane * 8 + e;
+      out[base] = hi; out[base + 512] = lo;
+    }
+  std::vector<float> r(out.size() / 2); memcpy(r.data(), out.data(), out.size() * 2); return r;
+}
+
 static void fill(std::vector<float>& v, unsigned seed) {
   unsigned s = seed * 2654435761u + 12345u;
   for (auto& x : v) { s = s * 1664525u + 1013904223u; x = ((s >> 8) & 0xffff) / 32768.0f - 1.0f; }
@@ -75,7 +90,8 @@ struct Shape { const char* name; int B, T, Cin, Cout, KW, dil; bool res, acc; fl
 int main(int argc, char** argv) {
   int reps = argc > 1 ? atoi(argv[1]) : 10;
   const char* filter = argc > 2 && strcmp(argv[2], "-") ? argv[2] : nullptr;
-  const int x3 = argc > 3 && !strcmp(argv[3], "x3");
+  const int x3 = argc > 3 && (!strcmp(argv[3], "x3") || !strcmp(argv[3], "x3f"));
+  const int frag = argc > 3 && !strcmp(argv[3], "x3f");
   hipStream_t s;
   CK(hipStreamCreate(&s));
   // ---- correctness on small awkward shapes
@@ -93,7 +109,9 @@ int main(int argc, char** argv) {
       CK(hipMalloc(&dout, nout * 4)); CK(hipMalloc(&dref, nout * 4)); CK(hipMalloc(&dlens, c.B * 4));
       std::vector<int> lens(c.B); for (int b = 0; b < c.B; ++b) lens[b] = c.T - 7 * b;
       float* dwx = nullptr;
+      float* dwf = nullptr;
       if (x3) { auto px = pack_x3(hw, c.Cout, c.KW, c.Cin); CK(hipMalloc(&dwx, px.size() * 4)); CK(hipMemcpy(dwx, px.data(), px.size() * 4, hipMemcpyHostToDevice)); }
+      if (frag) { auto pf = pack_x3_frag(hw, c.Cout, c.KW, c.Cin); CK(hipMalloc(&dwf, pf.size() * 4)); CK(hipMemcpy(dwf, pf.data(), pf.size() * 4, hipMemcpyHostToDevice)); }
       CK(hipMemcpy(din, hin.data(), nin * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(db, hb.data(), c.Cout * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dres, hres.data(), nout * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(dout, hout0.data(), nout * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dref, hout0.data(), nout * 4, hipMemcpyHostToDevice));
@@ -104,6 +122,7 @@ int main(int argc, char** argv) {
       p.in_slope = c.slope; p.act = ACT_LRELU; p.act_slope = 0.1f; p.accumulate = c.acc; p.out_div = c.acc ? 3.f : 1.f;
       ConvParams q = p; q.out = dref;
       if (x3) { p.w = dwx; p.x3 = 1; }
+      if (frag) p.wfrag = dwf;
       const char* m = launch_conv_gemm(p, s);
       if (m) { printf("%s: %s\n", c.name, m); return 1; }
       hipLaunchKernelGGL(naive_conv, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, q);
@@ -159,6 +178,7 @@ int main(int argc, char** argv) {
     p.in_ld = c.Cin; p.out_ld = c.Cout; p.res_ld = c.Cout; p.in_bs = (long long)c.T * c.Cin; p.out_bs = (long long)c.T * c.Cout; p.res_bs = p.out_bs;
     p.in_slope = c.slope; p.act = c.res ? ACT_NONE : ACT_LRELU; p.act_slope = 0.1f; p.accumulate = c.acc; p.out_div = 1.f;
     p.x3 = x3; if (x3) p.w = dwx3;
+    if (frag) p.wfrag = dwx3;  // timing only: any finite bf16 pattern, same footprint
     for (int i = 0; i < 2; ++i) { const char* m = launch_conv_gemm(p, s); if (m) { printf("%s: %s\n", c.name, m); return 1; } }
     CK(hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) launch_conv_gemm(p, s);

@@ -372,9 +372,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    // gfx9 counts loads and stores in one vmcnt; with stores possibly in flight hipcc turns every counted wait of the
-    // main loop into vmcnt(0).  Draining once per tile keeps the per-tap waits for the weight fragments counted.
-    if constexpr (BFRAG) __builtin_amdgcn_s_waitcnt(0x0F70);
   };
 
   __builtin_amdgcn_s_setprio(3);

@@ -71,6 +71,8 @@ def load_library() -> C.CDLL:
     lib.e2etts_set_precision.argtypes = [P, I, I]
     lib.e2etts_set_ragged.restype = I
     lib.e2etts_set_ragged.argtypes = [P, I]
+    lib.e2etts_set_fused_resblocks.restype = I
+    lib.e2etts_set_fused_resblocks.argtypes = [P, I]
     lib.e2etts_profile_enable.restype = I
     lib.e2etts_profile_enable.argtypes = [P, I]
     lib.e2etts_profile_read.restype = I
@@ -89,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "e2etts_version", "e2etts_last_error", "e2etts_create", "e2etts_destroy", "e2etts_load_weights", "e2etts_acoustic",
     "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
     "e2etts_fetch_wav", "e2etts_vocoder_stream_begin", "e2etts_vocoder_stream_push", "e2etts_vocoder_stream_fetch",
-    "e2etts_set_precision", "e2etts_set_ragged", "e2etts_profile_enable", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
+    "e2etts_set_precision", "e2etts_set_ragged", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
 ]
 
 
@@ -237,6 +239,10 @@ class Engine:
     def set_ragged(self, on: bool = True):
         """synthesize(): skip the rows of shorter utterances that no valid sample depends on (default on)."""
         self._check(self.lib.e2etts_set_ragged(self._h, 1 if on else 0), "e2etts_set_ragged")
+
+    def set_fused_resblocks(self, on: bool = True):
+        """bf16 modes: each ResBlock conv pair at 32 / 64 / 128 channels as one kernel (default on); results are bit-identical."""
+        self._check(self.lib.e2etts_set_fused_resblocks(self._h, 1 if on else 0), "e2etts_set_fused_resblocks")
 
     # ---- long-form / streaming vocoder
     def vocoder_stream(self, chunks, B: int, want_pcm: bool = False):

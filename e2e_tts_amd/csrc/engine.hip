@@ -90,6 +90,11 @@ struct e2etts_engine {
   ConvW mel_lin, voc_pre, voc_post;
   std::vector<ConvW> postnet, voc_up;
   std::vector<std::vector<ConvW>> rb_c1, rb_c2;  // [stage * n_kernels + j][dilation index]
+  // fused ResBlock pairs (resblock_pair.hip): conv1's fragment-order image followed by conv2's, per [stage * n_kernels + j][m];
+  // stage_fused[i]: every pair of stage i can run fused (channels 32 / 64 / 128)
+  std::vector<std::vector<float*>> rb_pair_frag;
+  std::vector<char> stage_fused;
+  int fuse_pairs = 1;  // e2etts_set_fused_resblocks
 
   // workspace
   DevBuf ids, lens64, lens32, spk, xa, xb, xs, xp, tmp, qkv, att, hid, p1, p2;
@@ -263,6 +268,11 @@ void free_frags(e2etts_engine* e) {
     (void)hipFree(kv.second);
   }
   e->frag_of.clear();
+  for (auto& v : e->rb_pair_frag)
+    for (float* f : v)
+      if (f) (void)hipFree(f);
+  e->rb_pair_frag.clear();
+  e->stage_fused.clear();
   e->dev_bytes -= e->frag_bytes;
   e->frag_bytes = 0;
 }
@@ -401,6 +411,8 @@ int bind_vocoder(e2etts_engine* e) {
   e->voc_up.resize(c.voc_stages);
   e->rb_c1.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
   e->rb_c2.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
+  e->rb_pair_frag.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
+  e->stage_fused.clear();
   uint64_t ch = C0;
   for (int i = 0; i < c.voc_stages; ++i) {
     const uint64_t cin = ch, cout = ch / 2, s = c.voc_up_rate[i];
@@ -415,6 +427,27 @@ int bind_vocoder(e2etts_engine* e) {
         std::string q = "voc.rb." + std::to_string(idx) + ".";
         RET(bind_conv(e, q + "c1." + std::to_string(m), ch, k, ch, e->rb_c1[idx][m]));
         RET(bind_conv(e, q + "c2." + std::to_string(m), ch, k, ch, e->rb_c2[idx][m]));
+      }
+    }
+    // fused pairs: all of a stage or none (the two forms use the stage's scratch buffers differently)
+    bool fusable = true;
+    for (int j = 0; j < c.voc_n_kernels; ++j)
+      for (int m = 0; m < c.voc_n_dil; ++m)
+        fusable = fusable && resblock_pair_supported((int)ch, c.voc_rb_kernel[j], c.voc_rb_dil[j][m]) &&
+                  e->rb_c1[i * c.voc_n_kernels + j][m].wx3 && e->rb_c2[i * c.voc_n_kernels + j][m].wx3;
+    e->stage_fused.push_back(fusable ? 1 : 0);
+    for (int j = 0; j < c.voc_n_kernels && fusable; ++j) {
+      const int idx = i * c.voc_n_kernels + j;
+      const int k = c.voc_rb_kernel[j];
+      for (int m = 0; m < c.voc_n_dil; ++m) {
+        const size_t one = x3_frag_bytes((int)ch, k, (int)ch);
+        float* f = nullptr;
+        HIPCHK(e, hipMalloc(&f, 2 * one));
+        e->dev_bytes += 2 * one;
+        e->frag_bytes += 2 * one;
+        e->rb_pair_frag[idx].push_back(f);
+        KCHK(e, launch_x3_to_frag(e->rb_c1[idx][m].wx3, f, (int)ch, k, (int)ch, e->stream));
+        KCHK(e, launch_x3_to_frag(e->rb_c2[idx][m].wx3, f + one / 4, (int)ch, k, (int)ch, e->stream));
       }
     }
   }
@@ -783,7 +816,32 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       const int idx = i * c.voc_n_kernels + j;
       const int k = c.voc_rb_kernel[j];
       const float* cur = XU;
-      for (int m = 0; m < c.voc_n_dil; ++m) {
+      const bool fused = e->fuse_pairs && e->voc_precision != E2ETTS_PRECISION_FP32 && e->stage_fused[i];
+      for (int m = 0; m < c.voc_n_dil && fused; ++m) {
+        // the whole pair in one launch (resblock_pair.hip); x and out must differ, so the running x ping-pongs CUR / T1
+        const bool last = m == c.voc_n_dil - 1;
+        PairParams q;
+        q.x = cur; q.wfrag = e->rb_pair_frag[idx][m]; q.b1 = e->rb_c1[idx][m].b; q.b2 = e->rb_c2[idx][m].b;
+        q.out = last ? S : (cur == CUR ? T1 : CUR);
+        q.act_rows = act_stage[i + 1];
+        q.B = B; q.T = (int)n; q.C = co; q.KW = k; q.dil = c.voc_rb_dil[j][m];
+        q.x_bs = q.out_bs = (long long)n * co;
+        q.slope = 0.1f; q.mode = e->voc_precision;
+        if (last) {
+          q.accumulate = j > 0;
+          if (j == c.voc_n_kernels - 1 && q.accumulate) q.out_div = (float)c.voc_n_kernels;
+        }
+        {
+          static const bool fine = getenv("E2ETTS_PROFILE_FINE") != nullptr;
+          char nm[48];
+          if (fine) snprintf(nm, sizeof nm, "pair %d k%d d%d r%lld%s", co, k, q.dil, (long long)B * n, q.accumulate ? "+a" : "");
+          else snprintf(nm, sizeof nm, "resblock_pair_%d", co);
+          ProfScope ps(e, nm, resblock_pair_flops(q), resblock_pair_bytes(q));
+          KCHK(e, launch_resblock_pair(q, e->stream));
+        }
+        cur = q.out;
+      }
+      for (int m = 0; m < c.voc_n_dil && !fused; ++m) {
         const int d = c.voc_rb_dil[j][m];
         // xt = c1(lrelu(x)); the lrelu that feeds c2 is applied here, in c1's epilogue (V/layers.py:35-38)
         p = ConvParams();
@@ -1145,6 +1203,13 @@ int e2etts_set_ragged(e2etts_engine* e, int enable) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
   e->ragged = enable != 0;
+  return E2ETTS_OK;
+}
+
+int e2etts_set_fused_resblocks(e2etts_engine* e, int enable) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->fuse_pairs = enable != 0;
   return E2ETTS_OK;
 }
 

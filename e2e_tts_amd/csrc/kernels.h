@@ -75,6 +75,27 @@ const char* launch_length_regulate(const float* x, const int32_t* cum, const int
 // out[b] = min(cap, (lens[b] + add) * mul): rows a layer has to compute for utterance b in ragged mode
 const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s);
 // [B, C, T] -> [B, T, C]
+// One (conv k, dilation d -> leaky ReLU -> conv k, dilation 1 -> + x) pair of a HiFi-GAN ResBlock1 in one launch
+// (resblock_pair.hip): out = c2(lrelu(c1(lrelu(x)) + b1)) + b2 + x, optionally (out_old + that) / out_div.
+struct PairParams {
+  const float* x = nullptr;      // [B, T, C] channels-last; also the residual
+  const float* wfrag = nullptr;  // conv1's fragment-order image followed by conv2's (launch_x3_to_frag, C x KW x C each)
+  const float* b1 = nullptr;     // [C]
+  const float* b2 = nullptr;     // [C]
+  float* out = nullptr;          // [B, T, C], must not alias x
+  const int32_t* act_rows = nullptr;  // optional [B]: only output rows < act_rows[b] are needed (whole tiles beyond are skipped)
+  int B = 0, T = 0, C = 0, KW = 0, dil = 1;
+  long long x_bs = 0, out_bs = 0;     // batch strides in floats
+  float slope = 0.1f;            // leaky-ReLU slope of both activations
+  int accumulate = 0;            // out = out_old + result
+  float out_div = 1.0f;          // then / out_div (needs accumulate)
+  int mode = 1;                  // 1: bf16x3 split precision, 2: plain bf16
+};
+bool resblock_pair_supported(int C, int KW, int dil);
+const char* launch_resblock_pair(const PairParams& p, hipStream_t s);
+double resblock_pair_flops(const PairParams& p);
+double resblock_pair_bytes(const PairParams& p);
+
 // split-precision weight image -> MFMA-fragment order (ConvParams::wfrag)
 const char* launch_x3_to_frag(const float* x3, float* frag, int Cout, int KW, int Cin, hipStream_t s);
 size_t x3_frag_bytes(int Cout, int KW, int Cin);

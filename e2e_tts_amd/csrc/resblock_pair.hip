@@ -1,0 +1,388 @@
+// resblock_pair: one (dilated conv -> leaky ReLU -> conv -> + x) pair of HiFi-GAN's ResBlock1 in ONE kernel.
+//
+// Reference V/layers.py:33-40:   xt = lrelu(x); xt = c1(xt); xt = lrelu(xt); xt = c2(xt); x = xt + x
+// (c1: kernel k, dilation d; c2: kernel k, dilation 1; both C -> C channels, "same" zero padding) and, for the last
+// pair of a ResBlock, the running sum over the parallel ResBlocks and its division by num_kernels
+// (V/generator.py:44-48).
+//
+// Why: as two conv_gemm launches the intermediate [B, T, C] tensor (805 MB per stage at B = 32) is written to and read
+// back from HBM, and the C = 32 / 64 stages and every k = 3 layer sit on the HBM roofline (profiles/r1: measured HBM
+// bytes = algorithmic bytes, 4.4-5.0 TB/s).  Here the intermediate never leaves the CU: conv1's accumulators are
+// split to bf16 hi | lo and written straight into LDS in A-operand layout, conv2 reads them as row-shifted views.
+// HBM traffic per pair: x in, out out (+ out in when accumulating) instead of 5-6 tensor passes.
+//
+// Arithmetic is the split-precision ("bf16x3") or plain-bf16 MFMA path of conv_gemm.hip, with the same operation order
+// per output element (chunk-major, tap, k-step; lo*hi, hi*lo, hi*hi), so the result is bit-identical to the two-launch
+// form (tests/test_gpu_parity.py compares them).  Weights come as MFMA fragments straight from L2 (launch_x3_to_frag).
+//
+// Geometry.  A workgroup (4 waves) owns BMI intermediate rows = BMI - (KW-1) output rows:
+//   x rows [o0 - pad2 - pad1, ... + BMI + (KW-1) d)  --conv1-->  intermediate rows [o0 - pad2, o0 - pad2 + BMI)
+//   --conv2-->  output rows [o0, o0 + BMI - (KW-1)).   The (KW-1)/BMI recompute is the price of the fusion (4 % at k = 11,
+//   BMI = 256).  Intermediate rows outside [0, T) are ZERO (conv2's zero padding), not conv1 of padding.
+// LDS: one region, first the x slab of one 32-channel chunk [(BMI + (KW-1) d) x 36 words], then -- conv1's accumulators
+// being complete -- overwritten by the intermediate [C/32][(BMI + KW - 1) x 36 words], then by the epilogue's transpose
+// patches.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace e2etts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int LDK = 36;        // LDS row: 32 bf16 hi | 32 bf16 lo | 16 B pad = 36 words
+constexpr int MAX_HALO1 = 64;  // (KW - 1) * dil of conv1
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const bf16x2 r = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32, round to nearest even
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  hi.x = pack_bf16(v.x, v.y);
+  hi.y = pack_bf16(v.z, v.w);
+  const float hx = __builtin_bit_cast(float, hi.x << 16), hy = __builtin_bit_cast(float, hi.x & 0xffff0000u);
+  const float hz = __builtin_bit_cast(float, hi.y << 16), hw = __builtin_bit_cast(float, hi.y & 0xffff0000u);
+  lo.x = pack_bf16(v.x - hx, v.y - hy);
+  lo.y = pack_bf16(v.z - hz, v.w - hw);
+}
+
+template <int BMI, int C, int WM, int WN, bool SPLIT, bool ACCUM>
+__global__ __launch_bounds__(256, 2) void resblock_pair_kernel(const PairParams p, const int tiles_per_block) {
+  constexpr int NCH = C / 32;                  // 32-channel chunks (K of both convs, and N tiles of the intermediate)
+  constexpr int NWN = C / WN;
+  constexpr int MT = WM / 32, NT = WN / 32;
+  static_assert((BMI / WM) * NWN == 4, "4 wavefronts per workgroup");
+  constexpr int AROWS = (BMI + MAX_HALO1 + 31) / 32;  // slab rows staged per thread (upper bound)
+  constexpr int ELD = WN + 4;                          // epilogue patch row stride (floats)
+  static_assert(4 * 16 * ELD <= BMI * LDK, "epilogue patches must fit in the region");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int KW = p.KW, dil = p.dil;
+  const int halo1 = dil * (KW - 1), pad1 = halo1 / 2, pad2 = (KW - 1) / 2;
+  const int BMO = BMI - (KW - 1);
+  const int irows = BMI + KW - 1;              // intermediate rows kept per chunk (the last KW-1 feed discarded outputs only)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+
+  const int b = blockIdx.y;
+  const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
+  const int mtiles = (t_act + BMO - 1) / BMO;
+  const int tile0 = blockIdx.x * tiles_per_block;
+  const int ntile = min(tiles_per_block, mtiles - tile0);
+  if (ntile <= 0) return;
+
+  const float* x_b = p.x + (long long)b * p.x_bs;
+  float* out_b = p.out + (long long)b * p.out_bs;
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x_b), 0, (int)((long long)p.T * C * 4), 0x00020000);
+  // fragment order [32-column tile][tap][chunk][k-step][hi|lo][lane][8 bf16]; conv2's image follows conv1's
+  const int frag_words = NCH * KW * NCH * 1024;  // 32-bit words of one conv's image
+  const __amdgpu_buffer_rsrc_t wf_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wfrag), 0, 2 * frag_words * 4, 0x00020000);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // ---- x slab staging (one 32-channel chunk): registers now, LDS later
+  float4 areg[AROWS];
+  bool aok[AROWS];
+  const int srows = BMI + halo1;
+  auto load_a = [&](int tile, int chunk) {
+    const int x0 = tile * BMO - pad2 - pad1;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int r = lrow + i * 32;
+      const int g = x0 + r;
+      aok[i] = r < srows && g >= 0 && g < p.T;
+      const int gc = min(max(g, 0), p.T - 1);
+      areg[i] = __builtin_bit_cast(
+          float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (gc * C + lc4) * 4, chunk * 128, 0));
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int r = lrow + i * 32;
+      if (r < srows) {
+        float4 v = aok[i] ? areg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x = fmaxf(v.x, v.x * p.slope); v.y = fmaxf(v.y, v.y * p.slope);
+        v.z = fmaxf(v.z, v.z * p.slope); v.w = fmaxf(v.w, v.w * p.slope);
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        uint2* row = reinterpret_cast<uint2*>(smem + r * LDK);
+        row[lc4 >> 2] = hi;        // 4 bf16 = 8 bytes at bf16 index lc4
+        row[8 + (lc4 >> 2)] = lo;  // lo half starts at byte 64
+      }
+    }
+  };
+
+  // ---- weight fragments: B operand of one k-step, one 1 KiB load per (32-column tile, hi | lo)
+  float4 bfr[2][NT][2];
+  auto load_frag = [&](int conv, int chunk, int j, int ks) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int hl = 0; hl < (SPLIT ? 2 : 1); ++hl) {
+        const int nt = wn * NT + n;
+        const int soff = (conv * frag_words + (((((nt * KW + j) * NCH + chunk) * 2 + ks) * 2 + hl) << 8)) * 4;
+        bfr[ks][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
+      }
+  };
+  // one tap of one chunk: 2 k-steps of 16, the fragments of k-step ks are re-requested for the next iteration (nconv, nchunk, nj)
+  // as soon as its MFMAs have been issued
+  auto mma_tap = [&](const float* a_base, int nconv, int nchunk, int nj) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[MT], al[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        ah[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + ks * 8));
+        if constexpr (SPLIT) al[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + 16 + ks * 8));
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[ks][n][0]);
+          if constexpr (SPLIT) {
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[ks][n][1]);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
+          }
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
+        }
+      // keep the request right behind the MFMAs that free its registers (left alone, hipcc sinks all requests to the end
+      // of the iteration, a few cycles before the next one waits for them)
+      __builtin_amdgcn_sched_barrier(0);
+      load_frag(nconv, nchunk, nj, ks);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- epilogue 1: intermediate = lrelu(acc + b1) (zero outside [0, T)), split, into LDS as conv2's A operand
+  // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float bias1[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) bias1[n] = p.b1[wn * WN + n * 32 + li];
+  auto epilogue1 = [&](int tile) {
+    const int i0 = tile * BMO - pad2;
+    unsigned short* inter = reinterpret_cast<unsigned short*>(smem);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int chunk = wn * NT + n;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int g = i0 + row;
+          float v = acc[m][n][r] + bias1[n];
+          v = fmaxf(v, v * p.slope);
+          v = (g >= 0 && g < p.T) ? v : 0.f;
+          const __bf16 h = (__bf16)v;
+          const __bf16 l = (__bf16)(v - (float)h);
+          unsigned short* dst = inter + ((chunk * irows + row) * LDK) * 2 + li;
+          dst[0] = __builtin_bit_cast(unsigned short, h);
+          if constexpr (SPLIT) dst[32] = __builtin_bit_cast(unsigned short, l);
+          acc[m][n][r] = 0.f;
+        }
+    }
+  };
+
+  // ---- epilogue 2: out = acc + b2 + x (+ out, / div), float4 through wave-private transpose patches
+  constexpr int LPR = WN / 4, RPP = 64 / LPR, PASSES = 16 / RPP;
+  const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+  const int ecol = wn * WN + pc4;
+  const float4 bias2 = *reinterpret_cast<const float4*>(p.b2 + ecol);
+  auto epilogue2 = [&](int tile) {
+    const int o0 = tile * BMO;
+    const int t_end = min(o0 + BMO, p.T);  // rows this tile owns
+    float* patch = smem + wave * (16 * ELD);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float4 resv[2][PASSES];  // residual rows of this 32-row block, requested before its transposes
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int t = min(o0 + wm * WM + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
+          resv[hh][ps] = *reinterpret_cast<const float4*>(x_b + (long long)t * C + ecol);
+        }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float4 accv[PASSES];  // accumulate mode: what the 16 output rows of this half hold now
+        if constexpr (ACCUM) {
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) {
+            const int t = min(o0 + wm * WM + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
+            accv[ps] = *reinterpret_cast<const float4*>(out_b + (long long)t * C + ecol);
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            const int r = hh * 8 + rr;
+            const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;
+            patch[row * ELD + n * 32 + li] = acc[m][n][r];
+          }
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int row = ps * RPP + prow;
+          const int t = o0 + wm * WM + m * 32 + hh * 16 + row;
+          float4 v = *reinterpret_cast<const float4*>(patch + row * ELD + pc4);
+          v.x += bias2.x; v.y += bias2.y; v.z += bias2.z; v.w += bias2.w;
+          const float4 rv = resv[hh][ps];
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+          if constexpr (ACCUM) {
+            const float4 ov = accv[ps];
+            v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+            if (p.out_div != 1.0f) {
+              v.x = v.x / p.out_div; v.y = v.y / p.out_div; v.z = v.z / p.out_div; v.w = v.w / p.out_div;
+            }
+          }
+          if (t < t_end) *reinterpret_cast<float4*>(out_b + (long long)t * C + ecol) = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  };
+
+  // ---- main
+  load_a(tile0, 0);
+  store_a();
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) load_frag(0, 0, 0, ks);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing in flight at the loop heads: their waits stay counted (see conv_gemm.hip)
+
+  for (int tl = 0; tl < ntile; ++tl) {
+    const int tile = tile0 + tl;
+    const bool more = tl + 1 < ntile;
+    // conv1: K = chunks of x, slab re-staged per chunk
+    for (int c = 0; c < NCH; ++c) {
+      if (c + 1 < NCH) load_a(tile, c + 1);
+      __syncthreads();  // slab of chunk c visible
+      const float* a0 = smem + (wm * WM + li) * LDK + lh * 4;
+      for (int j = 0; j < KW; ++j) {
+        const bool lastj = j + 1 == KW;
+        const bool lastc = c + 1 == NCH;
+        // next iteration in fragment order: next tap; else tap 0 of the next chunk; else conv2's first
+        const int nconv = (lastj && lastc) ? 1 : 0;
+        const int nchunk = lastj ? (lastc ? 0 : c + 1) : c;
+        const int nj = lastj ? 0 : j + 1;
+        mma_tap(a0 + j * dil * LDK, nconv, nchunk, nj);
+      }
+      if (c + 1 < NCH) {
+        __syncthreads();  // every wave is done with the slab of chunk c
+        store_a();
+      }
+    }
+    __syncthreads();  // x slab dead
+    epilogue1(tile);
+    // next tile's first slab flies behind conv2 -- except in the accumulate form at >= 64 channels, whose epilogue needs the
+    // registers for the rows it adds to (with both, hipcc spilled 50+ VGPRs and the launch ran 25-50 % longer)
+    constexpr bool EARLY_SLAB = !(ACCUM && C >= 64);
+    if (EARLY_SLAB && more) load_a(tile + 1, 0);
+    __syncthreads();  // intermediate visible
+    // conv2: K = chunks of the intermediate, dilation 1
+    for (int c = 0; c < NCH; ++c) {
+      const float* a0 = smem + (c * irows + wm * WM + li) * LDK + lh * 4;
+      for (int j = 0; j < KW; ++j) {
+        const bool lastj = j + 1 == KW;
+        const bool lastc = c + 1 == NCH;
+        const int nconv = (lastj && lastc) ? 0 : 1;  // after the last tap: conv1 of the next tile (same weights)
+        const int nchunk = lastj ? (lastc ? 0 : c + 1) : c;
+        const int nj = lastj ? 0 : j + 1;
+        mma_tap(a0 + j * LDK, nconv, nchunk, nj);
+      }
+    }
+    __syncthreads();  // intermediate dead: the region now carries the transpose patches
+    epilogue2(tile);
+    if (more) {
+      if (!EARLY_SLAB) load_a(tile + 1, 0);
+      __syncthreads();  // patches read back
+      store_a();
+    }
+  }
+}
+
+template <int BMI, int C, int WM, int WN, bool SPLIT>
+const char* launch_pair_cfg(const PairParams& p, hipStream_t s) {
+  const int halo1 = p.dil * (p.KW - 1);
+  const int BMO = BMI - (p.KW - 1);
+  const size_t words = (size_t)std::max((BMI + halo1) * LDK, (C / 32) * (BMI + p.KW - 1) * LDK);
+  const size_t lds = words * sizeof(float);
+  if (lds > 80 * 1024) return "resblock_pair: LDS region exceeds 80 KiB";
+  const int mtiles = (p.T + BMO - 1) / BMO;
+  const long long total = (long long)mtiles * p.B;
+  int tpb = (int)(total / (256 * 8));
+  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  if (tpb > mtiles) tpb = mtiles;
+  dim3 grid((mtiles + tpb - 1) / tpb, p.B);
+  if (p.accumulate)
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, true>), grid, dim3(256), lds, s, p, tpb);
+  else
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, false>), grid, dim3(256), lds, s, p, tpb);
+  return hipGetLastError() == hipSuccess ? nullptr : "resblock_pair: launch failed";
+}
+
+template <int BMI, int C, int WM, int WN>
+const char* launch_pair_mode(const PairParams& p, hipStream_t s) {
+  static bool attr_done = false;  // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_done = true;
+  }
+  return p.mode == 1 ? launch_pair_cfg<BMI, C, WM, WN, true>(p, s) : launch_pair_cfg<BMI, C, WM, WN, false>(p, s);
+}
+
+}  // namespace
+
+bool resblock_pair_supported(int C, int KW, int dil) {
+  return (C == 32 || C == 64 || C == 128) && (KW & 1) && KW >= 3 && KW <= 15 && dil >= 1 && dil * (KW - 1) <= MAX_HALO1;
+}
+
+double resblock_pair_flops(const PairParams& p) { return 2.0 * 2.0 * p.B * (double)p.T * p.C * p.KW * p.C; }
+
+double resblock_pair_bytes(const PairParams& p) {
+  return 4.0 * ((double)p.B * p.T * p.C * (2.0 + (p.accumulate ? 1 : 0)) + 2.0 * p.C * p.KW * p.C);
+}
+
+const char* launch_resblock_pair(const PairParams& p, hipStream_t s) {
+  if (!p.x || !p.wfrag || !p.b1 || !p.b2 || !p.out) return "resblock_pair: null pointer";
+  if (p.B <= 0 || p.T <= 0) return "resblock_pair: bad dims";
+  if (!resblock_pair_supported(p.C, p.KW, p.dil)) return "resblock_pair: unsupported channels / kernel / dilation";
+  if (p.mode != 1 && p.mode != 2) return "resblock_pair: mode must be 1 (bf16x3) or 2 (bf16)";
+  if (p.slope < 0.f || p.slope > 1.f) return "resblock_pair: slope must lie in [0, 1]";
+  if (p.out_div != 1.0f && !p.accumulate) return "resblock_pair: out_div needs accumulate";
+  if ((((uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.wfrag | (uintptr_t)p.b2) & 15) || (p.x_bs & 3) || (p.out_bs & 3))
+    return "resblock_pair: pointers must be 16-byte aligned";
+  if ((long long)p.T * p.C * 4 >= (1LL << 31)) return "resblock_pair: one utterance must stay below 2 GiB (32-bit buffer offsets)";
+  if (p.x == p.out) return "resblock_pair: in-place is not possible (tiles read their neighbours' rows)";
+  if (p.C == 32) return launch_pair_mode<256, 32, 64, 32>(p, s);
+  if (p.C == 64) return launch_pair_mode<256, 64, 64, 64>(p, s);
+  return launch_pair_mode<128, 128, 64, 64>(p, s);
+}
+
+}  // namespace e2etts

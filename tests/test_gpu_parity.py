@@ -222,3 +222,35 @@ def test_ragged_synthesize_is_bit_identical_on_valid_samples(name):
             ok = [np.abs(rag[b, :n].astype(np.int32) - ref_pcm[b, :n].astype(np.int32)) <= 1 for b, n in enumerate(mel_lens * hop)]
             assert np.concatenate(ok).mean() >= 0.999
     eng.set_ragged(True)
+
+
+@pytest.mark.parametrize("name", ["tiny_b3", "full_b3", "c3_mixed"])
+def test_fused_resblock_pairs_are_bit_identical(name):
+    """resblock_pair.hip (intermediate in LDS) against the same pair as two conv_gemm launches: same arithmetic in the same
+    order, so the PCM and the fp32 waveform must be equal bit for bit -- padded (vocoder) and ragged (synthesize)."""
+    g = load_golden(name)
+    cfg, eng = engine_for(g, name)
+    d, p, e = (float(x) for x in g["controls"])
+    spk = np.array([int(g["speaker"])], np.int64)
+    hop = cfg["audio"]["stft"]["hop_length"]
+    try:
+        for prec in ("bf16x3", "bf16"):
+            eng.set_precision(prec)
+            out = {}
+            for fused in (False, True):
+                eng.set_fused_resblocks(fused)
+                eng.set_ragged(False)
+                r = eng.acoustic(g["ids"], g["lens"], spk, d, p, e, want=("mel_lens",))
+                wav, pcm = eng.vocoder(None, r["B"], r["T"], pcm=True)
+                eng.set_ragged(True)
+                rag, mel_lens, _ = eng.synthesize(g["ids"], g["lens"], spk, d, p, e)
+                out[fused] = (wav, pcm, rag, mel_lens)
+            np.testing.assert_array_equal(out[True][0], out[False][0])
+            np.testing.assert_array_equal(out[True][1], out[False][1])
+            for b, n in enumerate(out[True][3] * hop):
+                np.testing.assert_array_equal(out[True][2][b, :n], out[False][2][b, :n])
+            if prec == "bf16x3" and "wav" in g:
+                assert mean_l1(out[True][0], g["wav"]) < WAV_L1
+    finally:
+        eng.set_fused_resblocks(True)
+        eng.set_precision("bf16x3")

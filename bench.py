@@ -34,7 +34,7 @@ PHONEMES = 128
 FRAMES_PER_PHONEME = 6
 
 
-CONV_CLASSES = ("conv_gemm", "conv_x3", "x3 ", "f32 ")  # the last two: per-layer classes under E2ETTS_PROFILE_FINE=1
+CONV_CLASSES = ("conv_gemm", "conv_x3", "resblock_pair", "x3 ", "f32 ", "pair ")  # the last two: per-layer classes under E2ETTS_PROFILE_FINE=1
 
 
 def log(*a):
@@ -209,12 +209,13 @@ def main():
             pass
         # fp32 kernel: algorithmic FLOPs against the fp32 MFMA peak.  Split-precision kernel: every algorithmic FLOP
         # costs three bf16 MFMA FLOPs, so its ceiling in algorithmic TFLOP/s is the bf16 dense peak / 3.
-        x3 = dom["name"].startswith("conv_x3")
+        x3 = dom["name"].startswith(("conv_x3", "resblock_pair", "x3 ", "pair "))
         peak = PEAK_BF16_TFLOPS / 3.0 if x3 else PEAK_FP32_TFLOPS
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 3), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "peak_note": ("bf16 dense MFMA peak 2500 / 3 MFMAs per split-precision product" if x3
-                                  else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                    "peak_note": ("bf16 dense MFMA peak 2500 / 3 MFMAs per split-precision product (nominal, at 2.4 GHz; under bf16 MFMA "
+                                  "load on random data the chip holds 1.8-1.9 GHz: MI355X_MICROARCH.md measures 1247-1483 TFLOP/s "
+                                  "for bare bf16 MFMA loops = 416-494 here)" if x3 else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                     "launches_per_step": dom["launches"] / args.steps,

@@ -22,6 +22,8 @@
 // both operands, so the k order inside an 8-wide group is permuted identically for A and B.
 // Epilogue: accumulators are transposed through a wave-private LDS patch (carved from the idle slab) so that
 // bias / residual / accumulate reads and the result store are float4, 256 B contiguous per 16 lanes.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace e2etts {
@@ -507,14 +509,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG>
 const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   const int halo = p.dil * (p.KW - 1);
-  const size_t lds = (size_t)((BM + halo) * LDK + 2 * BN * LDK) * sizeof(float);
+  static const int lds_pad = getenv("E2ETTS_LDS_PAD") ? atoi(getenv("E2ETTS_LDS_PAD")) : 0;  // tuning aid: occupancy experiments
+  const size_t lds = (size_t)((BM + halo) * LDK + (BFRAG ? 0 : 2 * BN * LDK)) * sizeof(float) + (BFRAG ? lds_pad : 0);
   if (lds > 64 * 1024) return "conv_gemm: LDS tile exceeds 64 KiB";
   const int mtiles = (p.T + BM - 1) / BM;
   const int ntiles = (p.Cout + BN - 1) / BN;
   // Persistent over M: enough workgroups for ~8 per CU, each walking up to 8 consecutive tiles.
   const long long total = (long long)mtiles * ntiles * p.B;
-  int tpb = (int)(total / (256 * 8));
-  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  static const int wg_per_cu = getenv("E2ETTS_WG_PER_CU") ? atoi(getenv("E2ETTS_WG_PER_CU")) : 8;  // tuning aid
+  int tpb = (int)(total / (256 * wg_per_cu));
+  tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
   if (tpb > mtiles) tpb = mtiles;
   dim3 grid((mtiles + tpb - 1) / tpb, ntiles, p.B);
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG>), grid, dim3(256), lds, s, p, tpb);

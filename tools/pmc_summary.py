@@ -28,8 +28,10 @@ def kernel_class(name: str):
     if m:
         bm, bn, mode = m.group(1), m.group(2), int(m.group(3))
         return ("conv_gemm_" if mode == 0 else "conv_x3_") + f"{bm}x{bn}"
-    for key, cls in (("attention_kernel", "attention"), ("layernorm_kernel", "layernorm"), ("conv_post_kernel", "conv_post"),
-                     ("resblock_pair_kernel", "resblock_pair")):
+    m = re.search(r"resblock_pair_kernel<\d+, (\d+)", name)
+    if m:
+        return "resblock_pair_" + m.group(1)
+    for key, cls in (("attention_kernel", "attention"), ("layernorm_kernel", "layernorm"), ("conv_post_kernel", "conv_post")):
         if key in name:
             return cls
     return None

@@ -11,7 +11,9 @@ Same constructor arguments, attributes (``hop_length``, ``sample_rate``, ``max_w
 * text -> phoneme ids defaults to ``e2e_tts_amd.g2p.text_to_sequence`` (a working restatement of the reference's
   Vietnamese g2p, pinned by a fixture converted with the reference's own code; the reference's ``text_to_sequence``
   cannot run as shipped: cleaners.py:12,26-30 recurses with a bad kwarg) and stays pluggable (``text_to_sequence=``);
-* no network call to a text normaliser (API/inference.py:28-33 swallows its failure anyway), no upload.
+* no network call to a text normaliser (API/inference.py:28-33 swallows its failure anyway), no upload;
+* ``speed != 1`` is served by the model's duration control instead of an ffmpeg ``atempo`` subprocess (``audio_speed_change``
+  keeps the reference's file-level signature on a WSOLA restatement; ffmpeg is absent, so that function is parity-unpinned).
 """
 from __future__ import annotations
 
@@ -200,6 +202,65 @@ def write_wav(path: str, audio: np.ndarray, samplerate: int) -> None:
         f.writeframes(np.ascontiguousarray(audio, dtype="<i2").tobytes())
 
 
+def read_wav(path: str):
+    """-> (int16 mono samples, sample rate) of a 16-bit PCM WAV (multi-channel files are averaged)."""
+    with wave.open(path, "rb") as f:
+        if f.getsampwidth() != 2:
+            raise ValueError("only 16-bit PCM WAV files are supported")
+        sr, ch = f.getframerate(), f.getnchannels()
+        a = np.frombuffer(f.readframes(f.getnframes()), dtype="<i2")
+    if ch > 1:
+        a = a.reshape(-1, ch).astype(np.int32).mean(axis=1).astype(np.int16)
+    return a, sr
+
+
+def time_stretch_wsola(x: np.ndarray, speed: float, sr: int = 22050, frame_ms: float = 40.0, search_ms: float = 10.0) -> np.ndarray:
+    """Tempo change without pitch change by waveform-similarity overlap-add (WSOLA, Verhelst & Roelands 1993) -- the family
+    of algorithm behind ffmpeg's ``atempo`` filter, which the reference shells out to (API/utils.py:163-172).  ffmpeg is not
+    part of this build, so this is a restatement of the published method, not of ffmpeg's code: *parity unpinned*.
+    Host-side utility, not on the GPU hot path (see ``Synthesizer.synthesis`` for the tempo control that is)."""
+    if not (0.25 <= speed <= 4.0):
+        raise ValueError("speed must lie in [0.25, 4]")
+    x = np.asarray(x, dtype=np.float64)
+    if speed == 1.0 or x.size == 0:
+        return x.copy()
+    n = max(int(sr * frame_ms / 1000.0) // 2 * 2, 64)      # frame length (even)
+    hop_out = n // 2                                       # 50 % overlap of Hann windows sums to one
+    hop_in = hop_out * speed
+    delta = max(int(sr * search_ms / 1000.0), 1)
+    win = np.hanning(n + 1)[:n]
+    n_frames = max(int(np.ceil((x.size / speed) / hop_out)), 1)
+    xp = np.concatenate([np.zeros(delta + n), x, np.zeros(2 * n + delta + int(hop_in) + 1)])
+    out = np.zeros(n_frames * hop_out + n)
+    pos = delta + n  # index in xp of the natural continuation of the previous frame
+    for i in range(n_frames):
+        target = int(round(i * hop_in)) + delta + n
+        if i == 0:
+            best = target
+        else:
+            # the candidate within +-delta of `target` that best continues what was just written (template = natural successor)
+            tmpl = xp[pos:pos + n]
+            lo = target - delta
+            seg = xp[lo:lo + n + 2 * delta]
+            corr = np.correlate(seg, tmpl, mode="valid")    # 2 delta + 1 lags
+            best = lo + int(np.argmax(corr))
+        out[i * hop_out:i * hop_out + n] += xp[best:best + n] * win
+        pos = best + hop_out
+    return out[: int(round(x.size / speed))]
+
+
+def audio_speed_change(input_path: str, output_path: str = None, speed_rate: float = 1.0) -> str:
+    """Same signature, output naming and return value as reference API/utils.py:163-172, without the ffmpeg subprocess:
+    reads the WAV, time-stretches it with ``time_stretch_wsola``, writes ``<input>_<speed>.<ext>``."""
+    if output_path is None:
+        file_type = input_path.split(".")[-1]
+        output_path = f"{input_path[:-len(file_type) - 1]}_{round(speed_rate, 2)}.{file_type}"
+    audio, sr = read_wav(input_path)
+    y = time_stretch_wsola(audio.astype(np.float64), float(speed_rate), sr)
+    write_wav(output_path, np.clip(np.rint(y), -32768, 32767).astype(np.int16), sr)
+    return output_path
+
+
 class Synthesizer:
     """reference e2e_tts/src/api/inference.py:12-50."""
 
@@ -211,14 +272,25 @@ class Synthesizer:
     def tts_to_file(self, text: str, file_path: str, speed: float = 1):
         return self.synthesis(text, file_path, speed)
 
-    def synthesis(self, text: str, save_filepath: str = None, speed: float = 1, speaker_id: str = "hn_minhphuong", sr: int = 22050):
+    def synthesis(self, text: str, save_filepath: str = None, speed: float = 1, speaker_id: str = "hn_minhphuong", sr: int = 22050,
+                  speed_mode: str = "duration"):
+        """reference API/inference.py:24-50.  ``speed != 1``: the reference synthesises at normal tempo and then runs ffmpeg's
+        ``atempo`` on the file (API/utils.py:163-172).  Here, by default (``speed_mode="duration"``), the tempo goes into the
+        model instead -- ``duration_control = 1 / speed`` (U/layers.py:218-221), i.e. the phonemes are simply generated shorter
+        or longer on the GPU path, with no vocoded-audio artefacts; ``speed_mode="wsola"`` post-processes the file like the
+        reference does (``audio_speed_change``).  Either way the returned path is named ``<file>_<speed>.wav`` as in the reference."""
         assert len(text) > 0
+        if speed_mode not in ("duration", "wsola"):
+            raise ValueError("speed_mode must be 'duration' or 'wsola'")
         if not save_filepath:
             save_filepath = os.path.join(self.output_dir, datetime.now().strftime("%m_%d_%Y_%H_%M_%S") + ".wav")
+        in_model = speed != 1 and speed_mode == "duration"
         audio = self.model.inference(texts=[text], speaker_id=speaker_id, pitch_control=1.0, energy_control=1.0,
-                                     duration_control=1.0, silence_distance=0.5)
+                                     duration_control=(1.0 / float(speed)) if in_model else 1.0, silence_distance=0.5)
+        if in_model:
+            file_type = save_filepath.split(".")[-1]
+            save_filepath = f"{save_filepath[:-len(file_type) - 1]}_{round(speed, 2)}.{file_type}"
         write_wav(save_filepath, audio, sr)
-        if speed != 1:
-            raise NotImplementedError("speed != 1 shells out to ffmpeg atempo in the reference (API/utils.py:163-172); "
-                                      "out of scope here -- use duration_control for tempo")
+        if speed != 1 and not in_model:
+            save_filepath = audio_speed_change(save_filepath, speed_rate=speed)
         return save_filepath

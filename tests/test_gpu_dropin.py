@@ -62,6 +62,20 @@ def test_tts_from_checkpoint_files_matches_oracle(tmp_path):
     import wave
     with wave.open(path) as f:
         assert f.getframerate() == 22050 and f.getsampwidth() == 2 and f.getnframes() > 22050 // 2
+        n1 = f.getnframes()
+    # speed != 1: tempo through the model's duration control (default) or WSOLA on the file (as the reference's ffmpeg atempo);
+    # both name the file <name>_<speed>.wav like reference API/utils.py:164-166 and change the duration, not the sample rate
+    silence = int(0.5 * 22050)
+    for mode in ("duration", "wsola"):
+        p2 = syn.synthesis("xin chao , viet nam", save_filepath=str(tmp_path / "out" / f"{mode}.wav"), speaker_id="spk_b", speed=2.0, speed_mode=mode)
+        assert p2.endswith(f"{mode}_2.0.wav")
+        with wave.open(p2) as f:
+            assert f.getframerate() == 22050
+            n2 = f.getnframes()
+        if mode == "wsola":
+            assert abs(n2 - n1 / 2) <= 2
+        else:  # speech halves (up to per-phoneme rounding), the 0.5 s of trailing silence does not
+            assert 0.3 * (n1 - silence) <= n2 - silence <= 0.7 * (n1 - silence)
 
 
 def test_model_mirrors_match_reference_fixture():

@@ -151,3 +151,28 @@ def test_engine_fails_loudly_without_gpu():
     dims = cfgmod.dims_from_config(cfgmod.tiny_config(), cfgmod.DEFAULT_STATS, 4)
     with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
         Engine(dims, 0)
+
+
+def test_wsola_time_stretch_and_wav_io(tmp_path):
+    """audio_speed_change (reference API/utils.py:163-172 shells out to ffmpeg atempo): duration scales by 1/speed, pitch
+    stays, naming follows the reference."""
+    from e2e_tts_amd.api import audio_speed_change, read_wav, time_stretch_wsola, write_wav
+    sr = 22050
+    t = np.arange(2 * sr) / sr
+    x = 8000.0 * np.sin(2 * np.pi * 220.0 * t) * (1 + 0.3 * np.sin(2 * np.pi * 3 * t))
+    np.testing.assert_array_equal(time_stretch_wsola(x, 1.0, sr), x)
+    for speed in (0.5, 0.8, 1.25, 2.0):
+        y = time_stretch_wsola(x, speed, sr)
+        assert y.size == round(x.size / speed)
+        spec = np.abs(np.fft.rfft(y * np.hanning(y.size)))
+        assert abs(np.fft.rfftfreq(y.size, 1 / sr)[int(np.argmax(spec))] - 220.0) < 2.0
+        assert 0.8 < np.abs(y).max() / np.abs(x).max() < 1.2
+    with pytest.raises(ValueError):
+        time_stretch_wsola(x, 8.0, sr)
+    src = str(tmp_path / "a.wav")
+    write_wav(src, x.astype(np.int16), sr)
+    back, sr2 = read_wav(src)
+    np.testing.assert_array_equal(back, x.astype(np.int16))
+    out = audio_speed_change(src, speed_rate=1.5)
+    assert out == str(tmp_path / "a_1.5.wav") and sr2 == sr
+    assert read_wav(out)[0].size == round(x.size / 1.5)

@@ -193,6 +193,11 @@ class Engine:
         self._check(self.lib.e2etts_fetch_tap(self._h, which.encode(), _addr(out), out.size), "e2etts_fetch_tap")
         return out
 
+    def fetch_tap_into(self, which: str, out) -> None:
+        """Like fetch_tap, into a caller buffer (numpy array or torch tensor, host or HBM)."""
+        n = out.size if isinstance(out, np.ndarray) else out.numel()
+        self._check(self.lib.e2etts_fetch_tap(self._h, which.encode(), _addr(out), n), "e2etts_fetch_tap")
+
     # ---- vocoder
     def vocoder(self, mel, B: int, T: int, channels_first=True, wav=True, pcm=False, out_wav=None, out_pcm=None):
         """mel: [B, n_mel, T] (channels_first) or [B, T, n_mel], or None for the resident mel_post."""

@@ -84,6 +84,18 @@ _DEFAULT = {
             "resblock_kernel_sizes": [3, 7, 11],
             "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
         },
+        # iSTFTNet (reference config/model_config.yaml:83-92): two upsampling stages, then an inverse STFT (n_fft 16, hop 4)
+        "istft": {
+            "resblock": 1,
+            "gen_istft_n_fft": 16,
+            "gen_istft_hop_size": 4,
+            "gen_istft_win_size": 16,
+            "upsample_rates": [8, 8],
+            "upsample_kernel_sizes": [16, 16],
+            "upsample_initial_channel": 512,
+            "resblock_kernel_sizes": [3, 7, 11],
+            "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+        },
     },
 }
 
@@ -119,6 +131,7 @@ def tiny_config() -> dict:
     fs["variance"]["variance_predictor"]["filter_size"] = 48
     fs["postnet"]["embedding_dim"] = 48
     c["models"]["hifigan"]["upsample_initial_channel"] = 64
+    c["models"]["istft"]["upsample_initial_channel"] = 64
     return c
 
 
@@ -165,6 +178,9 @@ class CEngineConfig(ctypes.Structure):
         ("pos_table_rows", ctypes.c_int32),
         ("f0_mean", ctypes.c_float),
         ("f0_std", ctypes.c_float),
+        ("voc_resblock", ctypes.c_int32),
+        ("voc_istft_nfft", ctypes.c_int32),
+        ("voc_istft_hop", ctypes.c_int32),
     ]
 
 
@@ -201,13 +217,21 @@ class EngineDims:
     pos_table_rows: int = 4096
     f0_mean: float = 0.0
     f0_std: float = 1.0
+    voc_resblock: int = 1     # 1: ResBlock1, 2: ResBlock2 (reference V/layers.py)
+    voc_istft_nfft: int = 0   # 0: HiFi-GAN tail; else iSTFTNet (reference V/generator.py:65-113)
+    voc_istft_hop: int = 0
 
     @property
     def upsample_total(self) -> int:
         t = 1
         for r in self.voc_up_rate:
             t *= r
-        return t
+        return t * (self.voc_istft_hop if self.voc_istft_nfft else 1)
+
+    @property
+    def voc_post_channels(self) -> int:
+        """conv_post output channels as stored in the blob: 1 (HiFi-GAN), or n_fft + 2 padded to a multiple of 4 (iSTFTNet)."""
+        return (self.voc_istft_nfft + 2 + 3) // 4 * 4 if self.voc_istft_nfft else 1
 
     def to_c(self) -> CEngineConfig:
         c = CEngineConfig()
@@ -219,6 +243,7 @@ class EngineDims:
             setattr(c, name, int(getattr(self, name)))
         c.f0_mean = float(self.f0_mean)
         c.f0_std = float(self.f0_std)
+        c.voc_resblock, c.voc_istft_nfft, c.voc_istft_hop = int(self.voc_resblock), int(self.voc_istft_nfft), int(self.voc_istft_hop)
         if len(self.voc_up_rate) > MAX_STAGES or len(self.voc_rb_kernel) > MAX_RESBLOCK_KERNELS:
             raise ValueError("vocoder config exceeds the C-ABI limits")
         c.voc_stages = len(self.voc_up_rate)
@@ -237,7 +262,7 @@ class EngineDims:
 
 
 def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int = N_SYMBOLS,
-                     pos_table_rows: int = 4096) -> EngineDims:
+                     pos_table_rows: int = 4096, vocoder: str = "hifigan") -> EngineDims:
     """Flatten the reference-style config dict into the engine dims.
 
     Raises for every configuration the hot path does not implement, naming the
@@ -245,7 +270,9 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
     something else.
     """
     fs = config["models"]["fastspeech2"]
-    hg = config["models"]["hifigan"]
+    if vocoder not in ("hifigan", "istft"):
+        raise ValueError("vocoder must be 'hifigan' or 'istft'")
+    hg = config["models"][vocoder]
     bt = fs["building_block"]["block_type"]
     if bt != "transformer":
         raise NotImplementedError(
@@ -269,8 +296,14 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         raise NotImplementedError("ffn_padding must be 'SAME'")
     if vp["pit_predictor_layers"] != vp["ener_predictor_layers"] or vp["pit_predictor_kernel"] != vp["ener_predictor_kernel"]:
         raise NotImplementedError("pitch and energy predictors must share depth/kernel")
-    if hg["resblock"] != 1:
-        raise NotImplementedError("only ResBlock1 (HiFi-GAN V1) is implemented (reference V/generator.py:19)")
+    # HifiGan picks ResBlock1 for `config['resblock'] == 1` (V/generator.py:19); iSTFT compares with the STRING '1'
+    # (V/generator.py:71), so the shipped yaml (an int) gives it ResBlock2 -- reproduced, checkpoints depend on it
+    rb1 = (hg["resblock"] == "1") if vocoder == "istft" else (hg["resblock"] == 1)
+    rb_dil = [list(d) for d in hg["resblock_dilation_sizes"]]
+    if not rb1:
+        rb_dil = [d[:2] for d in rb_dil]  # ResBlock2 uses dilation[0], dilation[1] only (V/layers.py:52-56)
+        if any(len(d) != 2 for d in rb_dil):
+            raise ValueError("ResBlock2 needs at least two dilations per kernel size")
     for k, u in zip(hg["upsample_kernel_sizes"], hg["upsample_rates"]):
         if k != 2 * u or u % 2:
             raise NotImplementedError("upsample kernel must be 2 x rate with even rate (polyphase 3-tap form)")
@@ -290,15 +323,23 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         voc_init_ch=hg["upsample_initial_channel"],
         voc_up_rate=list(hg["upsample_rates"]), voc_up_kernel=list(hg["upsample_kernel_sizes"]),
         voc_rb_kernel=list(hg["resblock_kernel_sizes"]),
-        voc_rb_dil=[list(d) for d in hg["resblock_dilation_sizes"]],
+        voc_rb_dil=rb_dil, voc_resblock=1 if rb1 else 2,
+        voc_istft_nfft=int(hg["gen_istft_n_fft"]) if vocoder == "istft" else 0,
+        voc_istft_hop=int(hg["gen_istft_hop_size"]) if vocoder == "istft" else 0,
         hop_length=hop, sample_rate=config["audio"]["signal"]["sampling_rate"],
         pos_table_rows=pos_table_rows,
         f0_mean=float(stats["f0"]["mean"]), f0_std=float(stats["f0"]["std"]),
     )
     if dims.ffn_k2 != 1:
         raise NotImplementedError("second FFN conv must be k=1")
+    if vocoder == "istft":
+        if hg["gen_istft_win_size"] != hg["gen_istft_n_fft"]:
+            raise NotImplementedError("gen_istft_win_size must equal gen_istft_n_fft")
+        n = dims.voc_istft_nfft
+        if n < 4 or n > 256 or n & (n - 1) or n % dims.voc_istft_hop:
+            raise NotImplementedError("gen_istft_n_fft must be a power of two in [4, 256] and a multiple of gen_istft_hop_size")
     if dims.upsample_total != hop:
-        raise ValueError(f"product of upsample_rates ({dims.upsample_total}) != hop_length ({hop})")
+        raise ValueError(f"product of upsample_rates (x iSTFT hop) ({dims.upsample_total}) != hop_length ({hop})")
     if dims.hidden % dims.n_head:
         raise ValueError("hidden not divisible by heads")
     return dims

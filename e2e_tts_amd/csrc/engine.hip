@@ -101,6 +101,9 @@ struct e2etts_engine {
   DevBuf logd, durf, cum, mel64, mel32, posbuf, ppred, epred, pidx, eidx;
   DevBuf dx, dxb, mel, melpost, pn1, pn2, encout;
   DevBuf melin, v0, v1, v2, v3, wav, pcm;
+  DevBuf istft_q, istft_ri, istft_sp;  // iSTFTNet tail: conv_post output, Re/Im per bin, exp / sin heads (tap "istft_spec_phase")
+  int istft_B = 0;
+  long long istft_F = 0;
   int64_t* h_mel = nullptr;  // pinned
   int last_B = 0, last_L = 0, last_T = 0, voc_B = 0, voc_T = 0;
   bool have_acoustic = false, have_wav = false;
@@ -425,13 +428,17 @@ int bind_vocoder(e2etts_engine* e) {
       e->rb_c2[idx].resize(c.voc_n_dil);
       for (int m = 0; m < c.voc_n_dil; ++m) {
         std::string q = "voc.rb." + std::to_string(idx) + ".";
+        if (c.voc_resblock == 2) {  // ResBlock2: one convolution per dilation (V/layers.py:52-56)
+          RET(bind_conv(e, q + "c." + std::to_string(m), ch, k, ch, e->rb_c1[idx][m]));
+          continue;
+        }
         RET(bind_conv(e, q + "c1." + std::to_string(m), ch, k, ch, e->rb_c1[idx][m]));
         RET(bind_conv(e, q + "c2." + std::to_string(m), ch, k, ch, e->rb_c2[idx][m]));
       }
     }
     // fused pairs: all of a stage or none (the two forms use the stage's scratch buffers differently)
-    bool fusable = true;
-    for (int j = 0; j < c.voc_n_kernels; ++j)
+    bool fusable = c.voc_resblock == 1;
+    for (int j = 0; j < c.voc_n_kernels && fusable; ++j)
       for (int m = 0; m < c.voc_n_dil; ++m)
         fusable = fusable && resblock_pair_supported((int)ch, c.voc_rb_kernel[j], c.voc_rb_dil[j][m]) &&
                   e->rb_c1[i * c.voc_n_kernels + j][m].wx3 && e->rb_c2[i * c.voc_n_kernels + j][m].wx3;
@@ -451,8 +458,13 @@ int bind_vocoder(e2etts_engine* e) {
       }
     }
   }
-  RET(get_tensor(e, "voc.post.w", 7 * ch, &e->voc_post.w));
-  RET(get_tensor(e, "voc.post.b", 1, &e->voc_post.b));
+  if (c.voc_istft_nfft) {  // conv_post to n_fft + 2 channels (padded to a multiple of 4 by the packer), V/generator.py:92
+    const uint64_t pc = ((uint64_t)c.voc_istft_nfft + 2 + 3) / 4 * 4;
+    RET(bind_conv(e, "voc.post", pc, 7, ch, e->voc_post));
+  } else {
+    RET(get_tensor(e, "voc.post.w", 7 * ch, &e->voc_post.w));
+    RET(get_tensor(e, "voc.post.b", 1, &e->voc_post.b));
+  }
   return E2ETTS_OK;
 }
 
@@ -762,8 +774,13 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     maxv = std::max(maxv, len * ch);
   }
   if (ch < 4 || (ch % 4)) return e->fail(E2ETTS_EINVAL, "final vocoder width %lld must be a positive multiple of 4", ch);
-  const long long nsamp = len;
+  const bool istft = c.voc_istft_nfft != 0;
+  const long long nsamp = istft ? len * c.voc_istft_hop : len;
   if (nsamp != (long long)T * c.hop_length) return e->fail(E2ETTS_EINVAL, "upsample product != hop_length");
+  if (istft) {
+    if (ragged_lens) return e->fail(E2ETTS_EINVAL, "ragged compute is not implemented for the iSTFT vocoder");
+    maxv += ch;  // the reflection-padded frame
+  }
   const size_t vb = (size_t)B * maxv * 4;
   RET(ensure(e, e->v0, vb));
   RET(ensure(e, e->v1, vb));
@@ -841,7 +858,23 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         }
         cur = q.out;
       }
-      for (int m = 0; m < c.voc_n_dil && !fused; ++m) {
+      for (int m = 0; m < c.voc_n_dil && c.voc_resblock == 2; ++m) {
+        // ResBlock2 (V/layers.py:59-63): x = c(lrelu(x)) + x per dilation; the last one adds into the stage sum
+        const bool last = m == c.voc_n_dil - 1;
+        p = ConvParams();
+        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.in = cur; setw(p, e->rb_c1[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
+        p.KW = k; p.dil = c.voc_rb_dil[j][m]; p.pad = (k * p.dil - p.dil) / 2; p.in_slope = 0.1f;
+        if (last) {
+          p.out = S;
+          p.accumulate = j > 0;
+          if (j == c.voc_n_kernels - 1 && p.accumulate) p.out_div = (float)c.voc_n_kernels;
+        } else {
+          p.out = cur == CUR ? T1 : CUR;  // never in place: other workgroups still read the rows around this tile
+        }
+        RET(conv(e, p));
+        cur = p.out;
+      }
+      for (int m = 0; m < c.voc_n_dil && !fused && c.voc_resblock == 1; ++m) {
         const int d = c.voc_rb_dil[j][m];
         // xt = c1(lrelu(x)); the lrelu that feeds c2 is applied here, in c1's epilogue (V/layers.py:35-38)
         p = ConvParams();
@@ -866,7 +899,29 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       }
     }
   }
-  {
+  if (istft) {
+    // x = leaky_relu(x) [slope 0.01]; ReflectionPad1d((1, 0)); conv_post; spec = exp(..), phase = sin(..) (V/generator.py:107-111);
+    // wav = istft(spec * exp(j phase), n_fft, hop, window = hann) (src/tools/stft.py:138-148)
+    const long long F = n + 1;
+    const int pc = (c.voc_istft_nfft + 2 + 3) / 4 * 4, bins = c.voc_istft_nfft / 2 + 1;
+    RET(ensure(e, e->istft_q, (size_t)B * F * pc * 4));
+    RET(ensure(e, e->istft_ri, (size_t)B * F * bins * 8));
+    RET(ensure(e, e->istft_sp, (size_t)B * F * bins * 2 * 4));
+    {
+      ProfScope ps(e, "misc", 0, 0);
+      KCHK(e, launch_reflect_lrelu(S, XU, B, n, (int)ch, 0.01f, e->stream));
+    }
+    p = ConvParams();
+    p.B = B; p.T = (int)F; p.in = XU; setw(p, e->voc_post); p.out = ptr<float>(e->istft_q); p.Cin = (int)ch; p.Cout = pc; p.KW = 7; p.pad = 3;
+    RET(conv(e, p));
+    {
+      ProfScope ps(e, "istft", 0, (double)B * F * pc * 4.0 + (double)B * nsamp * 6.0);
+      KCHK(e, launch_istft(ptr<float>(e->istft_q), pc, ptr<float>(e->istft_sp), ptr<float>(e->istft_ri), ptr<float>(e->wav),
+                           ptr<int16_t>(e->pcm), B, F, c.voc_istft_nfft, c.voc_istft_hop, e->stream));
+    }
+    e->istft_B = B;
+    e->istft_F = F;
+  } else {
     ProfScope ps(e, "conv_post", 2.0 * B * (double)n * 7 * ch, (double)B * n * (ch * 4.0 + 6.0));
     KCHK(e, launch_conv_post(S, e->voc_post.w, e->voc_post.b, ptr<float>(e->wav), ptr<int16_t>(e->pcm), B, n, (int)ch, 7, e->stream));
   }
@@ -898,6 +953,12 @@ int e2etts_create(int device_id, const e2etts_config* cfg, e2etts_engine** out) 
   for (int i = 0; i < c.voc_stages; ++i)
     if (c.voc_up_kernel[i] != 2 * c.voc_up_rate[i] || (c.voc_up_rate[i] & 1)) return bad("upsample kernel must be 2 x rate, rate even");
   if ((c.voc_init_ch >> c.voc_stages) < 4 || (c.voc_init_ch % (4 << c.voc_stages))) return bad("upsample_initial_channel too small for the stage count");
+  if (c.voc_resblock != 1 && c.voc_resblock != 2) return bad("voc_resblock must be 1 or 2");
+  if (c.voc_resblock == 2 && c.voc_n_dil != 2) return bad("ResBlock2 has exactly two dilated convolutions (voc_n_dil == 2)");
+  if (c.voc_istft_nfft != 0) {
+    const int n = c.voc_istft_nfft;
+    if (n < 4 || n > 256 || (n & (n - 1)) || c.voc_istft_hop <= 0 || n % c.voc_istft_hop) return bad("iSTFT: n_fft must be a power of two in [4, 256] and a multiple of the hop");
+  }
   if (c.n_bins != 256) return bad("n_bins must be 256");
   if (c.pos_table_rows < c.max_seq_len + 1) return bad("pos_table_rows must cover max_seq_len + 1");
   int ndev = 0;
@@ -1012,9 +1073,17 @@ int e2etts_fetch_tap(e2etts_engine* e, const char* which, float* out, size_t n_f
   if (!e || !which || !out) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(e, hipSetDevice(e->device));
-  if (!e->have_acoustic) return e->fail(E2ETTS_ESTATE, "no acoustic result resident");
   const void* src = nullptr;
   size_t n = 0;
+  if (!strcmp(which, "istft_spec_phase")) {
+    if (!e->cfg.voc_istft_nfft || !e->have_wav) return e->fail(E2ETTS_ESTATE, "no iSTFT vocoder result resident");
+    n = (size_t)e->istft_B * e->istft_F * (e->cfg.voc_istft_nfft + 2);
+    if (n_floats != n) return e->fail(E2ETTS_EINVAL, "tap '%s' holds %zu floats, caller asked for %zu", which, n, n_floats);
+    RET(copy_out(e, out, e->istft_sp.p, n * 4));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return E2ETTS_OK;
+  }
+  if (!e->have_acoustic) return e->fail(E2ETTS_ESTATE, "no acoustic result resident");
   if (!strcmp(which, "enc_out")) { src = e->encout.p; n = (size_t)e->last_B * e->last_L * e->cfg.hidden; }
   else if (!strcmp(which, "dec_out")) { src = e->dx.p; n = (size_t)e->last_B * e->last_T * e->cfg.hidden; }
   else return e->fail(E2ETTS_EKEY, "unknown tap '%s'", which);
@@ -1070,7 +1139,7 @@ int e2etts_synthesize(e2etts_engine* e, const int64_t* ids, const int64_t* lens,
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(e, hipSetDevice(e->device));
   if (B > 4096) return e->fail(E2ETTS_EINVAL, "B > 4096");
-  const bool ragged = e->ragged != 0;
+  const bool ragged = e->ragged != 0 && !e->cfg.voc_istft_nfft;
   RET(acoustic_impl(e, ids, lens, B, L, speaker, n_spk_ids, d_control, p_control, e_control, ragged));
   if (T_out) *T_out = e->last_T;
   RET(vocoder_impl(e, ptr<float>(e->melpost), B, e->last_T, false, true, ragged ? ptr<int32_t>(e->mel32) : nullptr));
@@ -1116,6 +1185,7 @@ int e2etts_vocoder_stream_begin(e2etts_engine* e, int B) {
   std::lock_guard<std::mutex> lk(e->mu);
   if (!e->voc_loaded) return e->fail(E2ETTS_ESTATE, "vocoder weights not loaded");
   if (B <= 0 || B > 4096) return e->fail(E2ETTS_EINVAL, "B out of range");
+  if (e->cfg.voc_istft_nfft) return e->fail(E2ETTS_EINVAL, "the streaming vocoder is not implemented for the iSTFT generator");
   e->st_B = B;
   e->st_carry_n = 0;
   e->st_emitted = 0;

@@ -100,6 +100,11 @@ double resblock_pair_bytes(const PairParams& p);
 const char* launch_x3_to_frag(const float* x3, float* frag, int Cout, int KW, int Cin, hipStream_t s);
 size_t x3_frag_bytes(int Cout, int KW, int Cin);
 
+// iSTFTNet tail: leaky ReLU + ReflectionPad1d((1, 0)) on channels-last frames; exp / sin heads, inverse STFT with overlap-add
+const char* launch_reflect_lrelu(const float* in, float* out, int B, long long n, int C, float slope, hipStream_t s);
+const char* launch_istft(const float* q, int ldq, float* specphase, float* ri, float* wav, int16_t* pcm, int B, long long F, int nfft,
+                         int hop, hipStream_t s);
+
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s);
 // wav = tanh(conv7(lrelu_0.01(x))) with Cout = 1; pcm = (int16)(int32)(wav * 32768)
 const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,

@@ -292,6 +292,74 @@ __global__ void x3_to_frag_kernel(const uint4* __restrict__ x3, uint4* __restric
   frag[g] = v;
 }
 
+// ---- iSTFTNet tail (reference V/generator.py:107-113 + src/tools/stft.py:138-148)
+// x = leaky_relu(x, 0.01); x = ReflectionPad1d((1, 0))(x): frame 0 of the padded signal is frame 1 of the input.
+__global__ void reflect_lrelu_kernel(const float4* __restrict__ in, float4* __restrict__ out, long long n, int c4, float slope) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index inside one padded utterance
+  const int b = blockIdx.y;
+  if (i >= (n + 1) * c4) return;
+  const long long f = i / c4;
+  const int c = (int)(i - f * c4);
+  const long long src = f == 0 ? 1 : f - 1;
+  float4 v = in[((long long)b * n + src) * c4 + c];
+  v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope); v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+  out[((long long)b * (n + 1) + f) * c4 + c] = v;
+}
+
+// spec = exp(q[:bins]), phase = sin(q[bins:2 bins]) (V/generator.py:110-111); X = spec * exp(j phase) (stft.py:141)
+__global__ void istft_prep_kernel(const float* __restrict__ q, int ldq, float* __restrict__ specphase, float2* __restrict__ ri,
+                                  long long total, int bins) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (b * F + f) * bins + k
+  if (i >= total) return;
+  const long long row = i / bins;
+  const int k = (int)(i - row * bins);
+  const float spec = expf(q[row * ldq + k]);
+  const float phase = sinf(q[row * ldq + bins + k]);
+  specphase[row * (2 * bins) + k] = spec;
+  specphase[row * (2 * bins) + bins + k] = phase;
+  ri[i] = make_float2(spec * cosf(phase), spec * sinf(phase));
+}
+
+// torch.istft(X, n_fft, hop, win_length = n_fft, window = hann_window(n_fft) [periodic], center = True): per frame the real
+// inverse DFT (1/N normalisation, imaginary parts of DC and Nyquist ignored), times the window, overlap-added, divided by the
+// overlap-added squared window, with n_fft/2 samples trimmed on both sides -> hop * (F - 1) samples.  One thread per sample.
+__global__ void istft_ola_kernel(const float2* __restrict__ ri, float* __restrict__ wav, int16_t* __restrict__ pcm, long long F,
+                                 int nfft, int hop, long long nsamp) {
+  extern __shared__ float tw[];  // cos(2 pi m / N), sin(2 pi m / N), window[m]
+  for (int m = threadIdx.x; m < nfft; m += blockDim.x) {
+    const float a = 6.283185307179586f * (float)m / (float)nfft;
+    tw[m] = cosf(a);
+    tw[nfft + m] = sinf(a);
+    tw[2 * nfft + m] = 0.5f - 0.5f * cosf(a);
+  }
+  __syncthreads();
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= nsamp) return;
+  const int bins = nfft / 2 + 1;
+  const long long np = n + nfft / 2;  // index before the centre trim
+  long long f_hi = np / hop;
+  if (f_hi > F - 1) f_hi = F - 1;
+  long long f_lo = (np - nfft + hop) / hop;  // smallest f with np - f hop <= nfft - 1
+  if (f_lo < 0) f_lo = 0;
+  float num = 0.f, den = 0.f;
+  for (long long f = f_lo; f <= f_hi; ++f) {
+    const int m = (int)(np - f * hop);
+    const float2* x = ri + ((long long)b * F + f) * bins;
+    float acc = x[0].x + ((m & 1) ? -x[bins - 1].x : x[bins - 1].x);
+    for (int k = 1; k < bins - 1; ++k) {
+      const int idx = (k * m) & (nfft - 1);  // n_fft is a power of two
+      acc += 2.0f * (x[k].x * tw[idx] - x[k].y * tw[nfft + idx]);
+    }
+    const float w = tw[2 * nfft + m];
+    num += w * (acc / (float)nfft);
+    den += w * w;
+  }
+  const float y = num / den;
+  if (wav) wav[(long long)b * nsamp + n] = y;
+  if (pcm) pcm[(long long)b * nsamp + n] = (int16_t)(int32_t)(y * 32768.0f);
+}
+
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
@@ -450,6 +518,29 @@ const char* launch_x3_to_frag(const float* x3, float* frag, int Cout, int KW, in
   hipLaunchKernelGGL(x3_to_frag_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s,
                      reinterpret_cast<const uint4*>(x3), reinterpret_cast<uint4*>(frag), Cout, KW, nchunk, groups);
   return CHECK_LAUNCH("x3_to_frag");
+}
+
+const char* launch_reflect_lrelu(const float* in, float* out, int B, long long n, int C, float slope, hipStream_t s) {
+  if (!in || !out) return "reflect_lrelu: null pointer";
+  if (C % 4 || n < 2) return "reflect_lrelu: channels must be a multiple of 4 and n >= 2";
+  const long long items = (n + 1) * (C / 4);
+  hipLaunchKernelGGL(reflect_lrelu_kernel, dim3((unsigned)((items + 255) / 256), B), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), n, C / 4, slope);
+  return CHECK_LAUNCH("reflect_lrelu");
+}
+
+const char* launch_istft(const float* q, int ldq, float* specphase, float* ri, float* wav, int16_t* pcm, int B, long long F, int nfft,
+                         int hop, hipStream_t s) {
+  if (!q || !specphase || !ri) return "istft: null pointer";
+  if (nfft < 4 || nfft > 256 || (nfft & (nfft - 1)) || hop <= 0 || nfft % hop || F < 2) return "istft: n_fft must be a power of two in [4, 256], hop must divide it";
+  const int bins = nfft / 2 + 1;
+  const long long total = (long long)B * F * bins;
+  hipLaunchKernelGGL(istft_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, ldq, specphase,
+                     reinterpret_cast<float2*>(ri), total, bins);
+  const long long nsamp = (long long)hop * (F - 1);
+  hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((nsamp + 255) / 256), B), dim3(256), 3 * nfft * sizeof(float), s,
+                     reinterpret_cast<const float2*>(ri), wav, pcm, F, nfft, hop, nsamp);
+  return CHECK_LAUNCH("istft");
 }
 
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s) {

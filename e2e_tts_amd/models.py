@@ -147,16 +147,18 @@ class UnsupervisedFastSpeech2(_EngineBacked):
     __call__ = forward
 
 
-def _vocoder_only_dims(hifigan_config: dict, n_mel: int = 80) -> EngineDims:
+def _vocoder_only_dims(hifigan_config: dict, n_mel: int = 80, vocoder: str = "hifigan") -> EngineDims:
     cfg = default_config()
-    cfg["models"]["hifigan"] = hifigan_config
+    cfg["models"][vocoder] = hifigan_config
     cfg["audio"]["mel"]["channels"] = n_mel
     hop = 1
     for r in hifigan_config["upsample_rates"]:
         hop *= r
+    if vocoder == "istft":
+        hop *= hifigan_config["gen_istft_hop_size"]
     cfg["audio"]["stft"]["hop_length"] = hop
     from .config import DEFAULT_STATS
-    return dims_from_config(cfg, DEFAULT_STATS, n_speakers=1)
+    return dims_from_config(cfg, DEFAULT_STATS, n_speakers=1, vocoder=vocoder)
 
 
 class HifiGan(_EngineBacked):
@@ -193,3 +195,53 @@ class HifiGan(_EngineBacked):
         return wav.unsqueeze(1)
 
     __call__ = forward
+
+
+class iSTFT(HifiGan):
+    """Mirror of reference ``models.vocoder.iSTFT`` (V/generator.py:65-118; iSTFTNet): same constructor,
+    ``load_state_dict`` / ``eval`` / ``to`` / ``remove_weight_norm``, ``forward(x) -> (spec, phase)``.
+
+    ``inference(x)`` additionally returns the waveform the reference obtains with ``inverse_stft(spec, phase, n_fft, hop,
+    win)`` (src/tools/stft.py:138-148) -- on the engine the exp / sin heads, the per-frame inverse DFT, the window and the
+    overlap-add are one tail after conv_post, so the waveform needs no second call.  ResBlock selection reproduces the
+    reference's comparison with the string '1' (V/generator.py:71): the shipped yaml's integer 1 selects ResBlock2."""
+
+    def __init__(self, config: dict, device=None):
+        _EngineBacked.__init__(self)
+        self.config = config
+        self.num_kernels = len(config["resblock_kernel_sizes"])
+        self.num_upsamples = len(config["upsample_rates"])
+        self.post_n_fft = config["gen_istft_n_fft"]
+        self._dims_cache = _vocoder_only_dims(config, vocoder="istft")
+        self._device = _device_index(device)
+
+    def _run(self, x):
+        torch = _torch()
+        eng = self._ensure_engine()
+        dev = torch.device("cuda", self._device)
+        x = torch.as_tensor(x, dtype=torch.float32).contiguous()
+        if x.dim() != 3 or x.shape[1] != self._dims_cache.n_mel:
+            raise ValueError(f"expected mel of shape [B, {self._dims_cache.n_mel}, T], got {tuple(x.shape)}")
+        B, _, T = x.shape
+        wav = torch.empty((B, T * self._dims_cache.hop_length), dtype=torch.float32, device=dev)
+        eng.vocoder(x, B, T, channels_first=True, out_wav=wav)
+        return eng, B, T, wav
+
+    def forward(self, x):
+        """x [B, 80, T] -> (spec [B, n_fft/2 + 1, F], phase [B, n_fft/2 + 1, F]) on the GPU, F = T * prod(upsample_rates) + 1."""
+        torch = _torch()
+        eng, B, T, _ = self._run(x)
+        up = 1
+        for r in self.config["upsample_rates"]:
+            up *= r
+        F, bins = T * up + 1, self.post_n_fft // 2 + 1
+        sp = torch.empty((B, F, 2 * bins), dtype=torch.float32, device=torch.device("cuda", self._device))
+        eng.fetch_tap_into("istft_spec_phase", sp)
+        sp = sp.transpose(1, 2)
+        return sp[:, :bins, :], sp[:, bins:, :]
+
+    __call__ = forward
+
+    def inference(self, x):
+        """x [B, 80, T] -> wav [B, 1, T * hop] (= inverse_stft(*forward(x)))."""
+        return self._run(x)[3].unsqueeze(1)

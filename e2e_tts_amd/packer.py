@@ -222,11 +222,25 @@ def _pack_vocoder(dims: EngineDims, V, out) -> None:
         for j in range(nk):
             idx = i * nk + j
             for m in range(len(dims.voc_rb_dil[j])):
+                if dims.voc_resblock == 2:  # ResBlock2: `convs.{m}` (reference V/layers.py:52-56)
+                    w, b = voc_weight(f"resblocks.{idx}.convs.{m}")
+                    put(f"voc.rb.{idx}.c.{m}", conv_rows(w), b, w.shape[2], w.shape[1])
+                    continue
                 for cs, short in (("convs1", "c1"), ("convs2", "c2")):
                     w, b = voc_weight(f"resblocks.{idx}.{cs}.{m}")
                     put(f"voc.rb.{idx}.{short}.{m}", conv_rows(w), b, w.shape[2], w.shape[1])
     w, b = voc_weight("conv_post")
-    out["voc.post.w"], out["voc.post.b"] = conv_rows(w), b
+    if dims.voc_istft_nfft:
+        # iSTFTNet: conv_post has n_fft + 2 output channels (V/generator.py:92); zero rows pad them to a multiple of 4 so that
+        # the convolution kernel's float4 epilogue applies
+        pc = dims.voc_post_channels
+        w2 = np.zeros((pc, w.shape[1] * w.shape[2]), np.float32)
+        w2[:w.shape[0]] = conv_rows(w)
+        b2 = np.zeros((pc,), np.float32)
+        b2[:w.shape[0]] = b
+        put("voc.post", w2, b2, w.shape[2], w.shape[1])
+    else:
+        out["voc.post.w"], out["voc.post.b"] = conv_rows(w), b
 
 
 def build_blob(tensors: Mapping[str, np.ndarray]) -> np.ndarray:

@@ -127,11 +127,15 @@ def acoustic_manifest(config: dict, n_speakers: int, n_symbols: int = N_SYMBOLS)
     return m
 
 
-def vocoder_manifest(config: dict) -> "OrderedDict[str, Tuple[Shape, str]]":
-    """name -> (shape, kind) for HifiGan.state_dict() (weight-normed: weight_g / weight_v)."""
-    hg = config["models"]["hifigan"]
+def vocoder_manifest(config: dict, vocoder: str = "hifigan") -> "OrderedDict[str, Tuple[Shape, str]]":
+    """name -> (shape, kind) for HifiGan.state_dict() / iSTFT.state_dict() (weight-normed: weight_g / weight_v).
+
+    ``vocoder="istft"``: reference V/generator.py:65-94 -- same trunk from ``config["models"]["istft"]``, conv_post with
+    n_fft + 2 output channels, and ResBlock2 (``resblocks.N.convs.{0,1}``) unless ``resblock == '1'`` (the string; :71)."""
+    hg = config["models"][vocoder]
     n_mel = config["audio"]["mel"]["channels"]
     C0 = hg["upsample_initial_channel"]
+    rb1 = (hg["resblock"] == "1") if vocoder == "istft" else (hg["resblock"] == 1)
     m: "OrderedDict[str, Tuple[Shape, str]]" = OrderedDict()
 
     def add_wn(prefix, vshape, kind="wn"):
@@ -147,10 +151,14 @@ def vocoder_manifest(config: dict) -> "OrderedDict[str, Tuple[Shape, str]]":
     for i in range(len(hg["upsample_rates"])):
         ch = C0 // 2 ** (i + 1)
         for j, (k, dil) in enumerate(zip(hg["resblock_kernel_sizes"], hg["resblock_dilation_sizes"])):
-            for cs in ("convs1", "convs2"):
-                for d in range(len(dil)):
-                    add_wn(f"resblocks.{i * nk + j}.{cs}.{d}", (ch, ch, k))
-    add_wn("conv_post", (1, ch, 7))
+            if rb1:
+                for cs in ("convs1", "convs2"):
+                    for d in range(len(dil)):
+                        add_wn(f"resblocks.{i * nk + j}.{cs}.{d}", (ch, ch, k))
+            else:
+                for d in range(2):
+                    add_wn(f"resblocks.{i * nk + j}.convs.{d}", (ch, ch, k))
+    add_wn("conv_post", ((hg["gen_istft_n_fft"] + 2) if vocoder == "istft" else 1, ch, 7))
     return m
 
 
@@ -237,9 +245,9 @@ def make_acoustic_state(config: dict, stats: dict, n_speakers: int, seed: int = 
                  frames_per_phoneme=frames_per_phoneme)
 
 
-def make_vocoder_state(config: dict, seed: int = 4321) -> "OrderedDict[str, np.ndarray]":
-    sd = _fill(vocoder_manifest(config), seed, stats=None, mode="fixed", frames_per_phoneme=0)
-    # keep the pre-tanh signal in the unsaturated range so waveform parity is informative
+def make_vocoder_state(config: dict, seed: int = 4321, vocoder: str = "hifigan") -> "OrderedDict[str, np.ndarray]":
+    sd = _fill(vocoder_manifest(config, vocoder), seed, stats=None, mode="fixed", frames_per_phoneme=0)
+    # keep the pre-tanh signal in the unsaturated range so waveform parity is informative (iSTFT: log-magnitudes of O(1))
     sd["conv_post.weight_g"] = (sd["conv_post.weight_g"] * 0.25).astype(np.float32)
     return sd
 

@@ -65,6 +65,10 @@ typedef struct e2etts_config {
   int32_t sample_rate;
   int32_t pos_table_rows; /* rows of the regenerated sinusoid table shipped in the blob */
   float f0_mean, f0_std;  /* stats.json "f0" (U/layers.py:152) */
+  int32_t voc_resblock;   /* 1: ResBlock1 (V/layers.py:11-40), voc_n_dil pairs; 2: ResBlock2 (V/layers.py:49-66), voc_n_dil = 2 single convs */
+  int32_t voc_istft_nfft; /* 0: HiFi-GAN tail (conv_post -> tanh, V/generator.py:49-51); else the iSTFTNet tail (V/generator.py:107-113 +
+                             src/tools/stft.py:138-148): conv_post to n_fft + 2 channels, exp / sin, inverse STFT */
+  int32_t voc_istft_hop;  /* iSTFT hop; prod(voc_up_rate) * voc_istft_hop == hop_length */
 } e2etts_config;
 
 typedef struct e2etts_engine e2etts_engine;
@@ -100,6 +104,8 @@ int e2etts_acoustic(e2etts_engine* engine, const int64_t* ids, const int64_t* le
 int e2etts_fetch_mel(e2etts_engine* engine, float* mel, float* mel_post);
 
 /* Debug / parity taps of the last e2etts_acoustic: which = "enc_out" [B, L, H] | "dec_out" [B, T, H]. */
+/* taps: "enc_out" [B, L, hidden], "dec_out" [B, T, hidden] (after e2etts_acoustic); "istft_spec_phase" [B, T * prod(voc_up_rate) + 1,
+ * n_fft + 2] = exp / sin heads of the iSTFTNet generator (reference iSTFT.forward's return values), after a vocoder call. */
 int e2etts_fetch_tap(e2etts_engine* engine, const char* which, float* out, size_t n_floats);
 
 /* Replaces: HifiGan.forward (V/generator.py:37-53) on mel [B, n_mel, T] (the reference layout,

@@ -268,6 +268,44 @@ def case_vocoder_micro(models):
     save("voc_micro_tiny", **arrays)
 
 
+def case_istft(models):
+    """iSTFTNet generator (V/generator.py:65-113) + the inverse STFT of src/tools/stft.py:138-148.  ``inverse_stft`` is taken
+    from the reference file with ``ast`` and executed as-is (the module itself imports librosa, which this image lacks)."""
+    import torch
+    print("[istft]", flush=True)
+    src = open(os.path.join(REF, "e2e_tts", "src", "tools", "stft.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "inverse_stft"]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "reference:stft.py:inverse_stft", "exec"), ns)
+    inverse_stft = ns["inverse_stft"]
+    torch.set_grad_enabled(False)
+    arrays = {}
+    cases = (("tiny_rb2", cfgmod.tiny_config(), 1, (2, 12), 51), ("tiny_rb1", cfgmod.tiny_config(), "1", (1, 9), 52),
+             ("full_rb2", cfgmod.default_config(), 1, (2, 10), 53))
+    for tag, config, resblock, (B, T), seed in cases:
+        config["models"]["istft"]["resblock"] = resblock
+        hg = config["models"]["istft"]
+        state = sw.make_vocoder_state(config, seed=4000 + seed, vocoder="istft")
+        g = models.iSTFT(hg)
+        g.load_state_dict(sw.to_torch(state), strict=True)   # proves the iSTFT state-dict manifest exact
+        g.eval()
+        mel = np.random.Generator(np.random.PCG64(seed)).standard_normal((B, 80, T)).astype(np.float32)
+        spec, phase = g(torch.from_numpy(mel))
+        wav = inverse_stft(spec, phase, n_fft=hg["gen_istft_n_fft"], hop_size=hg["gen_istft_hop_size"], win_size=hg["gen_istft_win_size"])
+        assert wav.shape == (B, 1, T * 256), wav.shape
+        arrays[f"{tag}.mel"] = mel
+        arrays[f"{tag}.spec"] = spec.numpy().copy()
+        arrays[f"{tag}.phase"] = phase.numpy().copy()
+        arrays[f"{tag}.wav"] = wav.numpy().copy()
+        arrays[f"{tag}.seed"] = np.array([4000 + seed])
+        arrays[f"{tag}.resblock_is_str"] = np.array([isinstance(resblock, str)])
+        o = orc.IstftOracle(state, config)
+        s2, p2 = o.forward(mel)
+        print(f"  {tag}: oracle vs reference spec {np.abs(s2 - arrays[f'{tag}.spec']).max():.2e} phase {np.abs(p2 - arrays[f'{tag}.phase']).max():.2e} "
+              f"wav {np.abs(o.inverse(s2, p2) - arrays[f'{tag}.wav']).max():.2e}", flush=True)
+    save("istft", **arrays)
+
+
 def case_tables(models):
     """Both sinusoid tables as the reference builds them (U/blocks/utils.py:14-34, U/sublayers.py:28-44)."""
     print("[tables]", flush=True)
@@ -414,6 +452,7 @@ def main():
         "host_loop": case_host_loop,
         "g2p": case_g2p,
         "voc_micro_tiny": lambda: case_vocoder_micro(models),
+        "istft": lambda: case_istft(models),
         "tiny_b3": lambda: case_model(models, "tiny_b3", tiny, "varied", [23, 17, 9], 1, (1.0, 1.0, 1.0), 100, 2e-3, "full"),
         "tiny_long": lambda: case_model(models, "tiny_long", tiny, "varied", [70, 33], 2, (1.0, 1.0, 1.0), 200, 2e-3, "full"),
         "tiny_ctl": lambda: case_model(models, "tiny_ctl", tiny, "varied", [12, 30, 30, 5], 0, (1.3, 0.9, 1.1), 300, 2e-3, "full"),

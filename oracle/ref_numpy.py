@@ -431,6 +431,72 @@ class VocoderOracle:
         return np.tanh(x)
 
 
+class IstftOracle(VocoderOracle):
+    """iSTFT.forward restated (V/generator.py:96-113) plus the inverse STFT the reference applies to its outputs
+    (src/tools/stft.py:138-148 = torch.istft with a periodic Hann window, center=True).
+
+    ResBlock1 only when ``config['resblock'] == '1'`` -- the STRING, as the reference compares (V/generator.py:71); the yaml
+    ships the int 1, which selects ResBlock2 (V/layers.py:49-66, dilations d[0], d[1])."""
+
+    def __init__(self, state: Dict[str, np.ndarray], config: dict, dtype=np.float32):
+        cfg = {"models": {"hifigan": config["models"]["istft"]}}
+        super().__init__(state, cfg, dtype)
+        self.n_fft = int(self.hg["gen_istft_n_fft"])
+        self.hop = int(self.hg["gen_istft_hop_size"])
+        self.rb1 = self.hg["resblock"] == "1"
+
+    def resblock2(self, idx: int, x: np.ndarray, k: int, dils: Sequence[int]) -> np.ndarray:
+        w = self.w
+        for m in range(2):
+            d = dils[m]
+            xt = leaky_relu(x, LRELU_SLOPE)
+            xt = conv1d(xt, w[f"resblocks.{idx}.convs.{m}.weight"], w[f"resblocks.{idx}.convs.{m}.bias"],
+                        padding=int((k * d - d) / 2), dilation=d)
+            x = xt + x
+        return x
+
+    def forward(self, mel_bct: np.ndarray):
+        """mel [B, 80, T] -> (spec [B, n_fft/2 + 1, F], phase [B, n_fft/2 + 1, F]), F = T * prod(upsample_rates) + 1."""
+        hg, w = self.hg, self.w
+        x = conv1d(mel_bct.astype(self.dt), w["conv_pre.weight"], w["conv_pre.bias"], padding=3)
+        nk = len(hg["resblock_kernel_sizes"])
+        for i, (u, k) in enumerate(zip(hg["upsample_rates"], hg["upsample_kernel_sizes"])):
+            x = leaky_relu(x, LRELU_SLOPE)
+            x = conv_transpose1d(x, w[f"ups.{i}.weight"], w[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+            xs = None
+            for j in range(nk):
+                rb = self.resblock if self.rb1 else self.resblock2
+                r = rb(i * nk + j, x, hg["resblock_kernel_sizes"][j], hg["resblock_dilation_sizes"][j])
+                xs = r if xs is None else xs + r
+            x = xs / self.dt(nk)
+        x = leaky_relu(x, 0.01)                                   # F.leaky_relu default slope (:107)
+        x = np.concatenate([x[:, :, 1:2], x], axis=2)             # nn.ReflectionPad1d((1, 0)) (:94, :108)
+        x = conv1d(x, w["conv_post.weight"], w["conv_post.bias"], padding=3)
+        bins = self.n_fft // 2 + 1
+        return np.exp(x[:, :bins, :]), np.sin(x[:, bins:, :])      # (:110-111)
+
+    def inverse(self, spec: np.ndarray, phase: np.ndarray) -> np.ndarray:
+        """torch.istft(spec * exp(1j * phase), n_fft, hop, win_length = n_fft, window = hann_window(n_fft)) -> [B, 1, hop (F - 1)]
+        (src/tools/stft.py:138-148): per-frame irfft, times the window, overlap-add, divided by the overlap-added squared
+        window, n_fft // 2 samples trimmed at both ends (center=True)."""
+        n, hop = self.n_fft, self.hop
+        B, _, F = spec.shape
+        X = spec.astype(np.float64) * np.exp(1j * phase.astype(np.float64))
+        frames = np.fft.irfft(X, n=n, axis=1)                       # [B, n, F]
+        win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)    # torch.hann_window(n): periodic
+        total = n + hop * (F - 1)
+        y = np.zeros((B, total))
+        env = np.zeros(total)
+        for m in range(n):                                          # overlap-add, one window position at a time
+            y[:, m:m + hop * F:hop][:, :F] += frames[:, m, :] * win[m]
+            env[m:m + hop * F:hop][:F] += win[m] ** 2
+        y = y[:, n // 2:n // 2 + hop * (F - 1)] / env[n // 2:n // 2 + hop * (F - 1)]
+        return y[:, None, :].astype(self.dt)
+
+    def wav(self, mel_bct: np.ndarray) -> np.ndarray:
+        return self.inverse(*self.forward(mel_bct))
+
+
 # --------------------------------------------------------------------------- host loop (API/utils.py)
 
 def arrange_text(text: List[str], max_len: int = 300) -> List[str]:

@@ -254,3 +254,29 @@ def test_fused_resblock_pairs_are_bit_identical(name):
     finally:
         eng.set_fused_resblocks(True)
         eng.set_precision("bf16x3")
+
+
+@pytest.mark.parametrize("tag", ["tiny_rb2", "tiny_rb1", "full_rb2"])
+def test_istft_vocoder_matches_reference(tag):
+    """iSTFTNet on the engine (ResBlock2 / ResBlock1 trunk, reflection pad, conv_post to n_fft + 2 channels, exp / sin heads,
+    inverse STFT with overlap-add) against outputs of the reference's iSTFT module + inverse_stft."""
+    from test_oracle_golden import _istft_case
+    from e2e_tts_amd.models import iSTFT
+    import torch
+    g = load_golden("istft")
+    cfg, state = _istft_case(g, tag)
+    v = iSTFT(cfg["models"]["istft"], device=0)
+    v.load_state_dict(state)
+    v.eval()
+    mel = g[f"{tag}.mel"]
+    for prec, bar in (("fp32", 2e-6), ("bf16x3", 2e-5)):
+        v._ensure_engine().set_precision(prec)
+        spec, phase = v(torch.from_numpy(mel))
+        wav = v.inference(torch.from_numpy(mel))
+        assert tuple(wav.shape) == g[f"{tag}.wav"].shape
+        assert mean_l1(spec.cpu().numpy(), g[f"{tag}.spec"]) < bar * 10, prec
+        assert mean_l1(phase.cpu().numpy(), g[f"{tag}.phase"]) < bar * 10, prec
+        assert mean_l1(wav.cpu().numpy(), g[f"{tag}.wav"]) < bar, prec
+    eng = v._ensure_engine()
+    with pytest.raises(ValueError):  # streaming is a HiFi-GAN-tail feature
+        next(eng.vocoder_stream(iter([np.zeros((1, 4, 80), np.float32)]), 1))

@@ -119,9 +119,14 @@ def test_config_rejects_unimplemented_variants():
     with pytest.raises(NotImplementedError):
         cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4)
     cfg = cfgmod.default_config()
-    cfg["models"]["hifigan"]["resblock"] = 2
+    cfg["models"]["hifigan"]["resblock"] = 2   # ResBlock2: implemented (two dilations per kernel size)
+    assert cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4).voc_rb_dil == [[1, 3]] * 3
+    d = cfgmod.dims_from_config(cfgmod.default_config(), cfgmod.DEFAULT_STATS, 4, vocoder="istft")
+    assert (d.voc_resblock, d.voc_istft_nfft, d.voc_istft_hop, d.voc_post_channels, d.upsample_total) == (2, 16, 4, 20, 256)
+    cfg = cfgmod.default_config()
+    cfg["models"]["istft"]["gen_istft_win_size"] = 8
     with pytest.raises(NotImplementedError):
-        cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4)
+        cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4, vocoder="istft")
     cfg = cfgmod.default_config()
     cfg["audio"]["stft"]["hop_length"] = 300
     with pytest.raises(ValueError):
@@ -140,7 +145,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert ctypes.sizeof(cfgmod.CEngineConfig) == 4 * (23 + 8 + 8 + 1 + 4 + 1 + 16 + 3) + 8
+    assert ctypes.sizeof(cfgmod.CEngineConfig) == 4 * (23 + 8 + 8 + 1 + 4 + 1 + 16 + 3) + 8 + 4 * 3  # + voc_resblock, voc_istft_nfft, voc_istft_hop
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -116,3 +116,27 @@ def test_host_loop_matches_reference():
     np.testing.assert_array_equal([g["stress_lens"][order[s]] for s, _ in spans], g["stress_batch_first_len"])
     pcm = orc.combine_audio([g["ca_audio0"], g["ca_audio1"], g["ca_audio2"]], g["ca_lengths"], int(g["ca_distance"]))
     np.testing.assert_array_equal(pcm, g["ca_pcm"])
+
+
+def _istft_case(g, tag):
+    from e2e_tts_amd import config as cfgmod, synth_weights as sw
+    cfg = cfgmod.tiny_config() if tag.startswith("tiny") else cfgmod.default_config()
+    cfg["models"]["istft"]["resblock"] = "1" if bool(g[f"{tag}.resblock_is_str"][0]) else 1
+    state = sw.make_vocoder_state(cfg, seed=int(g[f"{tag}.seed"][0]), vocoder="istft")
+    return cfg, state
+
+
+@pytest.mark.parametrize("tag", ["tiny_rb2", "tiny_rb1", "full_rb2"])
+def test_istft_oracle_matches_reference(tag):
+    """iSTFTNet generator + inverse STFT (reference V/generator.py:65-113, src/tools/stft.py:138-148), incl. the ResBlock2
+    selected by the reference's comparison with the string '1'."""
+    from oracle import ref_numpy as orc
+    g = load_golden("istft")
+    cfg, state = _istft_case(g, tag)
+    o = orc.IstftOracle(state, cfg)
+    assert o.rb1 == bool(g[f"{tag}.resblock_is_str"][0])
+    spec, phase = o.forward(g[f"{tag}.mel"])
+    np.testing.assert_allclose(spec, g[f"{tag}.spec"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(phase, g[f"{tag}.phase"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(o.inverse(g[f"{tag}.spec"], g[f"{tag}.phase"]), g[f"{tag}.wav"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(o.wav(g[f"{tag}.mel"]), g[f"{tag}.wav"], rtol=0, atol=5e-6)

@@ -587,7 +587,13 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
     if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 2>(p, s);
     return launch_cfg<256, 32, 64, 32, 2>(p, s);
   }
-  if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 0>(p, s);
+  if (p.Cout > 64) {
+    // few rows (the encoder and the variance adaptor see B * L phonemes, not B * T frames): 128 x 128 tiles would leave most
+    // CUs idle, 64 x 64 tiles give 4x the workgroups
+    const long long wgs = (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B;
+    if (wgs < 2 * 256) return launch_cfg<64, 64, 32, 32, 0>(p, s);
+    return launch_cfg<128, 128, 64, 64, 0>(p, s);
+  }
   if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 0>(p, s);
   return launch_cfg<256, 32, 64, 32, 0>(p, s);
 }

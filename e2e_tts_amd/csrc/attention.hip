@@ -142,9 +142,189 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+// ---- split-precision ("bf16x3") form, for the decoder when its FFT blocks run in that arithmetic (the encoder keeps the
+// fp32 kernel above: its output decides durations and buckets).  Same flash-style structure and the same orientation trick,
+// on v_mfma_f32_32x32x16_bf16: every fp32 operand is hi + lo (two bf16) and a product keeps lo*hi + hi*lo + hi*hi.
+//   S^T = K . Q^T : A = K rows from LDS as [key][hi d | lo d], B = Q fragments in registers (lane = query, 8 consecutive d).
+//   O^T += V^T . P^T : the lane already holds P for keys k(r) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); the order of k inside an
+//   MFMA is free as long as A agrees, so V is staged TRANSPOSED with its keys permuted into that order:
+//   Vt[d][slot], slot = 16 s + 8 (lane >> 5) + e  <->  key k(8 s + e) + 4 (lane >> 5): the A fragment is one 16-byte read.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  const bf16x2_t r = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, r);
+}
+// 8 floats -> hi and lo fragments (8 bf16 each)
+__device__ __forceinline__ void split8(const float* v, bf16x8_t& hi, bf16x8_t& lo) {
+  uint4 h, l;
+  unsigned* hp = reinterpret_cast<unsigned*>(&h);
+  unsigned* lp = reinterpret_cast<unsigned*>(&l);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hp[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+    const float h0 = __builtin_bit_cast(float, hp[i] << 16), h1 = __builtin_bit_cast(float, hp[i] & 0xffff0000u);
+    lp[i] = pk_bf16(v[2 * i] - h0, v[2 * i + 1] - h1);
+  }
+  hi = __builtin_bit_cast(bf16x8_t, h);
+  lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           const int32_t* __restrict__ lens, int N, int H, float temperature) {
+  constexpr int KS = DK + 4;   // words per K row: DK/2 (hi bf16) + DK/2 (lo bf16) + 4 pad; KS mod 64 == 4 -> conflict-free b128
+  constexpr int VS = 36;       // words per Vt row: 16 (32 hi slots) + 16 (32 lo slots) + 4 pad
+  constexpr int DT = DK / 32;  // 32-wide tiles of the head dimension
+  constexpr int NS = DK / 16;  // k-steps of S^T = K . Q^T
+  static_assert(DK % 32 == 0, "head dim must be a multiple of 32");
+  __shared__ __attribute__((aligned(16))) unsigned Kh[32 * KS];
+  __shared__ __attribute__((aligned(16))) unsigned Vt[DK * VS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int len = min(lens ? lens[b] : N, N);
+  const int ld = 3 * H;
+  const float* base = qkv + (long long)b * N * ld;
+  const float* qp = base + head * DK;
+  const float* kp = base + H + head * DK;
+  const float* vp = base + 2 * H + head * DK;
+
+  // Q fragments: lane (query li, half lh) holds Q[q][16 s + 8 lh .. + 7] for every k-step s, split once
+  bf16x8_t qh[NS], ql[NS];
+  {
+    const int qrow = min(q0 + li, N - 1);
+    const float* qr = qp + (long long)qrow * ld + lh * 8;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(qr + s * 16), c = *reinterpret_cast<const float4*>(qr + s * 16 + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+      split8(v, qh[s], ql[s]);
+    }
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nchunks = (len + 31) / 32;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    __syncthreads();
+    for (int i = tid; i < 32 * (DK / 4); i += 256) {
+      const int r = i / (DK / 4), c4 = i % (DK / 4);
+      const int key = kc * 32 + r;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (key < N) {
+        kv = *reinterpret_cast<const float4*>(kp + (long long)key * ld + c4 * 4);
+        vv = *reinterpret_cast<const float4*>(vp + (long long)key * ld + c4 * 4);
+      }
+      // K row: [hi d 0 .. DK-1 | lo d 0 .. DK-1] as bf16
+      const unsigned k0 = pk_bf16(kv.x, kv.y), k1 = pk_bf16(kv.z, kv.w);
+      const float kx = __builtin_bit_cast(float, k0 << 16), ky = __builtin_bit_cast(float, k0 & 0xffff0000u);
+      const float kz = __builtin_bit_cast(float, k1 << 16), kw = __builtin_bit_cast(float, k1 & 0xffff0000u);
+      *reinterpret_cast<uint2*>(Kh + r * KS + c4 * 2) = make_uint2(k0, k1);
+      *reinterpret_cast<uint2*>(Kh + r * KS + DK / 2 + c4 * 2) = make_uint2(pk_bf16(kv.x - kx, kv.y - ky), pk_bf16(kv.z - kz, kv.w - kw));
+      // V transposed, key r -> slot: r = k(rr) + 4 h with rr = (r & 3) + 4 (r >> 3), h = (r >> 2) & 1; slot = 16 (rr >> 3) + 8 h + (rr & 7)
+      const int rr = (r & 3) + 4 * (r >> 3), h = (r >> 2) & 1;
+      const int slot = 16 * (rr >> 3) + 8 * h + (rr & 7);
+      unsigned short* vt = reinterpret_cast<unsigned short*>(Vt) + (c4 * 4) * (VS * 2) + slot;
+      const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 hb = (__bf16)vs[e];
+        const __bf16 lb = (__bf16)(vs[e] - (float)hb);
+        vt[e * (VS * 2)] = __builtin_bit_cast(unsigned short, hb);
+        vt[e * (VS * 2) + 32] = __builtin_bit_cast(unsigned short, lb);
+      }
+    }
+    __syncthreads();
+
+    // S^T[key][query] = sum_d K[key][d] Q[query][d]
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const unsigned* ka = Kh + li * KS + lh * 4;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ka + ks * 8));
+      const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ka + DK / 2 + ks * 8));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], s, 0, 0, 0);
+    }
+    // scale, key-padding mask, online softmax (per query = per lane, both lane halves hold the same query)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = s[r] / temperature;
+      v = key < len ? v : -INFINITY;
+      s[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);  // finite: chunk kc has at least one valid key
+    const float corr = expf(m_run - m_new);
+    float psum = 0.f;
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pv[r] = expf(s[r] - m_new);
+      psum += pv[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+    // P fragments: k-step s2 takes registers 8 s2 .. 8 s2 + 7 (their keys are what the Vt slots of that step hold)
+    bf16x8_t ph[2], pl[2];
+    split8(pv, ph[0], pl[0]);
+    split8(pv + 8, ph[1], pl[1]);
+    // O^T[d][query] = O^T * corr + sum_key V[key][d] P[key][query]
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= corr;
+      const unsigned* va = Vt + (d * 32 + li) * VS + lh * 4;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(va + s2 * 8));
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(va + 16 + s2 * 8));
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph[s2], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl[s2], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph[s2], o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  // O^T tile d: column = query (lane & 31), row = head-dim offset (r & 3) + 8 (r >> 2) + 4 lh -> 4 x float4 per tile
+  const int q = q0 + li;
+  if (q < N) {
+    const bool valid = q < len;
+    const float inv = valid ? 1.0f / l_run : 0.f;
+    float* orow = out + ((long long)b * N + q) * H + head * DK + 4 * lh;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        v.x = valid ? o[d][4 * g + 0] * inv : 0.f;
+        v.y = valid ? o[d][4 * g + 1] * inv : 0.f;
+        v.z = valid ? o[d][4 * g + 2] * inv : 0.f;
+        v.w = valid ? o[d][4 * g + 3] * inv : 0.f;
+        *reinterpret_cast<float4*>(orow + d * 32 + 8 * g) = v;
+      }
+  }
+}
+
 }  // namespace
 
-const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head,
+const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head, int x3,
                              hipStream_t s) {
   if (!qkv || !out) return "attention: null pointer";
   if (B <= 0 || N <= 0 || n_head <= 0 || H % n_head) return "attention: bad dims";
@@ -153,6 +333,17 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
   // reference: temperature = np.power(d_k, 0.5), scores divided by it in fp32 (U/blocks/transformer.py:201,254)
   const float temperature = (float)sqrt((double)dk);
   dim3 grid((N + 127) / 128, n_head, B);
+  if (x3) {
+    switch (dk) {
+      case 32: hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 64: hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 96: hipLaunchKernelGGL(attention_x3_kernel<96>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 128: hipLaunchKernelGGL(attention_x3_kernel<128>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 192: hipLaunchKernelGGL(attention_x3_kernel<192>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
+    }
+    return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
+  }
   switch (dk) {
     case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
     case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;

@@ -503,8 +503,8 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     RET(conv(e, p));
     {
       const double fl = 4.0 * B * c.n_head * (double)N * N * (H / c.n_head);
-      ProfScope ps(e, "attention", fl, 4.0 * 4.0 * B * N * H);
-      KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, e->stream));
+      ProfScope ps(e, sx ? "attention_x3" : "attention", fl, 4.0 * 4.0 * B * N * H);
+      KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, sx ? 1 : 0, e->stream));
     }
     // fc + residual (:238-239), LayerNorm eps 1e-5, masked_fill (:182-183)
     p = ConvParams(); p.B = B; p.T = N; p.act_rows = act;

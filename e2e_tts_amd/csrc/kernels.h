@@ -40,7 +40,7 @@ double conv_gemm_bytes(const ConvParams& p);
 // Fused masked self-attention on the packed QKV buffer of one FFT block.
 // qkv [B, N, 3H] (q | k | v, head h at columns h*dk .. (h+1)*dk of each third); keys >= lens[b] masked (-inf);
 // out [B, N, H]; query rows >= lens[b] are written as 0 (they are zeroed after the LayerNorm anyway).
-const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head,
+const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head, int x3,
                              hipStream_t s);
 
 // y[row, :] = LayerNorm(x[row, :]) * gamma + beta; rows t >= lens[b] -> 0 when lens != null (C <= 1024, C % 4 == 0)

@@ -27,11 +27,11 @@ def kernel_class(name: str):
     m = re.search(r"conv_gemm_kernel<(\d+), (\d+), \d+, \d+, (\d+)", name)
     if m:
         bm, bn, mode = m.group(1), m.group(2), int(m.group(3))
-        return ("conv_gemm_" if mode == 0 else "conv_x3_") + f"{bm}x{bn}"
+        return ("conv_gemm_" if mode == 0 else "conv_x3_") + f"{bm}x{bn}"  # bench.py's classes
     m = re.search(r"resblock_pair_kernel<\d+, (\d+)", name)
     if m:
         return "resblock_pair_" + m.group(1)
-    for key, cls in (("attention_kernel", "attention"), ("layernorm_kernel", "layernorm"), ("conv_post_kernel", "conv_post")):
+    for key, cls in (("attention_x3_kernel", "attention_x3"), ("attention_kernel", "attention"), ("layernorm_kernel", "layernorm"), ("conv_post_kernel", "conv_post")):
         if key in name:
             return cls
     return None

@@ -34,6 +34,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const int b = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int len = min(lens ? lens[b] : N, N);
+  if (blockIdx.x * 128 >= len) {  // a tile of padded queries only: their rows are zero (ragged batches)
+    for (int i = tid; i < 128 * (DK / 4); i += 256) {
+      const int q = blockIdx.x * 128 + i / (DK / 4);
+      if (q < N) *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + (i % (DK / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   const int ld = 3 * H;
   const float* base = qkv + (long long)b * N * ld;
   const float* qp = base + head * DK;
@@ -187,6 +194,13 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
   const int b = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int len = min(lens ? lens[b] : N, N);
+  if (blockIdx.x * 128 >= len) {  // a tile of padded queries only: their rows are zero (ragged batches)
+    for (int i = tid; i < 128 * (DK / 4); i += 256) {
+      const int q = blockIdx.x * 128 + i / (DK / 4);
+      if (q < N) *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + (i % (DK / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   const int ld = 3 * H;
   const float* base = qkv + (long long)b * N * ld;
   const float* qp = base + head * DK;

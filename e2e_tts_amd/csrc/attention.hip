@@ -247,14 +247,16 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
       // V transposed, key r -> slot: r = k(rr) + 4 h with rr = (r & 3) + 4 (r >> 3), h = (r >> 2) & 1; slot = 16 (rr >> 3) + 8 h + (rr & 7)
       const int rr = (r & 3) + 4 * (r >> 3), h = (r >> 2) & 1;
       const int slot = 16 * (rr >> 3) + 8 * h + (rr & 7);
-      unsigned short* vt = reinterpret_cast<unsigned short*>(Vt) + (c4 * 4) * (VS * 2) + slot;
+      // head-dim row d = 4 c4 + e lives at physical row (d & 3) (DK / 4) + (d >> 2) = e (DK / 4) + c4: consecutive lanes
+      // (consecutive c4) then write consecutive rows, 36 words apart.  Stored by row d they were 4 rows = 144 words = 16 banks apart.
+      unsigned short* vt = reinterpret_cast<unsigned short*>(Vt) + c4 * (VS * 2) + slot;
       const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const __bf16 hb = (__bf16)vs[e];
         const __bf16 lb = (__bf16)(vs[e] - (float)hb);
-        vt[e * (VS * 2)] = __builtin_bit_cast(unsigned short, hb);
-        vt[e * (VS * 2) + 32] = __builtin_bit_cast(unsigned short, lb);
+        vt[e * (DK / 4) * (VS * 2)] = __builtin_bit_cast(unsigned short, hb);
+        vt[e * (DK / 4) * (VS * 2) + 32] = __builtin_bit_cast(unsigned short, lb);
       }
     }
     __syncthreads();
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     for (int d = 0; d < DT; ++d) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[d][r] *= corr;
-      const unsigned* va = Vt + (d * 32 + li) * VS + lh * 4;
+      const unsigned* va = Vt + ((li & 3) * (DK / 4) + d * 8 + (li >> 2)) * VS + lh * 4;  // physical row of head-dim row d * 32 + li
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(va + s2 * 8));

@@ -577,21 +577,23 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
     if (p.x3 == 2) return launch_cfg_impl<128, 128, 64, 64, 2, false, false, false>(p, s);
     return launch_cfg_impl<128, 128, 64, 64, 0, false, false, false>(p, s);
   }
+  // few rows (small batches, the B = 1 latency path): 64 x 64 tiles give 4x the workgroups of 128 x 128
+  const bool few = p.Cout > 64 && (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B < 2 * 256;
   if (p.x3 == 1) {
+    if (few) return launch_cfg<64, 64, 32, 32, 1>(p, s);
     if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 1>(p, s);
     if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 1>(p, s);
     return launch_cfg<256, 32, 64, 32, 1>(p, s);
   }
   if (p.x3 == 2) {
+    if (few) return launch_cfg<64, 64, 32, 32, 2>(p, s);
     if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 2>(p, s);
     if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 2>(p, s);
     return launch_cfg<256, 32, 64, 32, 2>(p, s);
   }
   if (p.Cout > 64) {
-    // few rows (the encoder and the variance adaptor see B * L phonemes, not B * T frames): 128 x 128 tiles would leave most
-    // CUs idle, 64 x 64 tiles give 4x the workgroups
-    const long long wgs = (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B;
-    if (wgs < 2 * 256) return launch_cfg<64, 64, 32, 32, 0>(p, s);
+    // (the encoder and the variance adaptor see B * L phonemes, not B * T frames: always few rows)
+    if (few) return launch_cfg<64, 64, 32, 32, 0>(p, s);
     return launch_cfg<128, 128, 64, 64, 0>(p, s);
   }
   if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 0>(p, s);

@@ -238,8 +238,9 @@ int prof_collect(e2etts_engine* e) {
   } while (0)
 
 const char* conv_cfg_name(const ConvParams& p) {
-  if (p.x3) return p.Cout > 64 ? "conv_x3_128x128" : (p.Cout > 32 ? "conv_x3_256x64" : "conv_x3_256x32");
-  if (p.Cout > 64) return (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B < 512 ? "conv_gemm_64x64" : "conv_gemm_128x128";
+  const bool few = p.Cout > 64 && (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B < 512;
+  if (p.x3) return few ? "conv_x3_64x64" : (p.Cout > 64 ? "conv_x3_128x128" : (p.Cout > 32 ? "conv_x3_256x64" : "conv_x3_256x32"));
+  if (p.Cout > 64) return few ? "conv_gemm_64x64" : "conv_gemm_128x128";
   return p.Cout > 32 ? "conv_gemm_256x64" : "conv_gemm_256x32";
 }
 

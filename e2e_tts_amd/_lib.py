@@ -75,6 +75,8 @@ def load_library() -> C.CDLL:
     lib.e2etts_set_fused_resblocks.argtypes = [P, I]
     lib.e2etts_profile_enable.restype = I
     lib.e2etts_profile_enable.argtypes = [P, I]
+    lib.e2etts_profile_filter.restype = I
+    lib.e2etts_profile_filter.argtypes = [P, C.c_char_p]
     lib.e2etts_profile_read.restype = I
     lib.e2etts_profile_read.argtypes = [P, C.POINTER(KernelStat), I]
     lib.e2etts_device_bytes.restype = SZ
@@ -91,7 +93,7 @@ EXPORTED_SYMBOLS = [
     "e2etts_version", "e2etts_last_error", "e2etts_create", "e2etts_destroy", "e2etts_load_weights", "e2etts_acoustic",
     "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
     "e2etts_fetch_wav", "e2etts_vocoder_stream_begin", "e2etts_vocoder_stream_push", "e2etts_vocoder_stream_fetch",
-    "e2etts_set_precision", "e2etts_set_ragged", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
+    "e2etts_set_precision", "e2etts_set_ragged", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_filter", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
 ]
 
 
@@ -275,6 +277,10 @@ class Engine:
     # ---- profiling
     def profile_enable(self, on: bool = True):
         self._check(self.lib.e2etts_profile_enable(self._h, 1 if on else 0), "e2etts_profile_enable")
+
+    def profile_filter(self, kernel_class=None):
+        """Bracket only launches of this kernel class with events (None: all)."""
+        self._check(self.lib.e2etts_profile_filter(self._h, kernel_class.encode() if kernel_class else None), "e2etts_profile_filter")
 
     def profile_read(self):
         arr = (KernelStat * 256)()

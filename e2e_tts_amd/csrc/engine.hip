@@ -119,6 +119,7 @@ struct e2etts_engine {
 
   // profiling
   bool prof_on = false;
+  std::string prof_filter;  // non-empty: only launches of this class are bracketed by events (e2etts_profile_filter)
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   std::vector<e2etts_kernel_stat> prof_stats;
@@ -197,6 +198,7 @@ struct ProfScope {
   ProfRec rec{};
   bool on;
   ProfScope(e2etts_engine* e_, const char* name, double flops, double bytes) : e(e_), on(e_->prof_on) {
+    if (on && !e->prof_filter.empty() && e->prof_filter != name) on = false;
     if (!on) return;
     rec.cls = prof_class(e, name);
     rec.flops = flops;
@@ -1282,6 +1284,13 @@ int e2etts_set_fused_resblocks(e2etts_engine* e, int enable) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
   e->fuse_pairs = enable != 0;
+  return E2ETTS_OK;
+}
+
+int e2etts_profile_filter(e2etts_engine* e, const char* kernel_class) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->prof_filter = kernel_class ? kernel_class : "";
   return E2ETTS_OK;
 }
 

@@ -171,6 +171,9 @@ typedef struct e2etts_kernel_stat {
   double flops;   /* algorithmic FLOPs (2 x MAC) of those launches */
   double bytes;   /* algorithmic bytes (operands read once + result written once) */
 } e2etts_kernel_stat;
+/* Restrict the event bracketing to one kernel class (NULL or "": all classes).  Two hipEventRecord per launch cost ~8 us; with ~155
+ * launches per step that is 2 % of a step, so a timed region that only needs the dominant kernel's duration brackets that class alone. */
+int e2etts_profile_filter(e2etts_engine* engine, const char* kernel_class);
 int e2etts_profile_enable(e2etts_engine* engine, int enable);
 int e2etts_profile_read(e2etts_engine* engine, e2etts_kernel_stat* out, int cap);
 

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float inv_temp = 1.0f / temperature;  // split-precision path: a multiply and the hardware exp are within its error budget
 
   const int nchunks = (len + 31) / 32;
   for (int kc = 0; kc < nchunks; ++kc) {
@@ -279,19 +280,19 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float v = s[r] / temperature;
+      float v = s[r] * inv_temp;
       v = key < len ? v : -INFINITY;
       s[r] = v;
       mx = fmaxf(mx, v);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);  // finite: chunk kc has at least one valid key
-    const float corr = expf(m_run - m_new);
+    const float corr = __expf(m_run - m_new);
     float psum = 0.f;
     float pv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      pv[r] = expf(s[r] - m_new);
+      pv[r] = __expf(s[r] - m_new);
       psum += pv[r];
     }
     psum += __shfl_xor(psum, 32);
@@ -350,6 +351,16 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
   const float temperature = (float)sqrt((double)dk);
   dim3 grid((N + 127) / 128, n_head, B);
   if (x3) {
+    switch (dk) {
+        case 32: hipLaunchKernelGGL((attention_x3s_kernel<32, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+        case 64: hipLaunchKernelGGL((attention_x3s_kernel<64, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+        case 96: hipLaunchKernelGGL((attention_x3s_kernel<96, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+        case 128: hipLaunchKernelGGL((attention_x3s_kernel<128, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+        case 192: hipLaunchKernelGGL((attention_x3s_kernel<192, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+        default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
+      }
+      return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
+    }
     switch (dk) {
       case 32: hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
       case 64: hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;

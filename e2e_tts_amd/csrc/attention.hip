@@ -352,16 +352,6 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
   dim3 grid((N + 127) / 128, n_head, B);
   if (x3) {
     switch (dk) {
-        case 32: hipLaunchKernelGGL((attention_x3s_kernel<32, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-        case 64: hipLaunchKernelGGL((attention_x3s_kernel<64, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-        case 96: hipLaunchKernelGGL((attention_x3s_kernel<96, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-        case 128: hipLaunchKernelGGL((attention_x3s_kernel<128, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-        case 192: hipLaunchKernelGGL((attention_x3s_kernel<192, 4>), g16, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-        default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
-      }
-      return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
-    }
-    switch (dk) {
       case 32: hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
       case 64: hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
       case 96: hipLaunchKernelGGL(attention_x3_kernel<96>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;

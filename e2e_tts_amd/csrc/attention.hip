@@ -11,6 +11,7 @@
 //   - the probabilities are already the B operand of O^T += V^T . P^T: register r of lane half h holds key
 //     k0(r) + 4h, k0(r) = (r & 3) + 8 (r >> 2), and MFMA step r consumes exactly the key pair {k0(r), k0(r) + 4}.
 #include <math.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -178,8 +179,10 @@ __device__ __forceinline__ void split8(const float* v, bf16x8_t& hi, bf16x8_t& l
   lo = __builtin_bit_cast(bf16x8_t, l);
 }
 
-template <int DK>
-__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+// NW: wavefronts (32 queries each) per workgroup.  Every workgroup of an (utterance, head) pulls ALL its K / V chunks through L2, and that
+// traffic, not arithmetic, is what the staging costs: 8 waves = 256 queries per workgroup halve it against 4.
+template <int DK, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                            const int32_t* __restrict__ lens, int N, int H, float temperature) {
   constexpr int KS = DK + 4;   // words per K row: DK/2 (hi bf16) + DK/2 (lo bf16) + 4 pad; KS mod 64 == 4 -> conflict-free b128
   constexpr int VS = 36;       // words per Vt row: 16 (32 hi slots) + 16 (32 lo slots) + 4 pad
@@ -192,11 +195,11 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
   const int len = min(lens ? lens[b] : N, N);
-  if (blockIdx.x * 128 >= len) {  // a tile of padded queries only: their rows are zero (ragged batches)
-    for (int i = tid; i < 128 * (DK / 4); i += 256) {
-      const int q = blockIdx.x * 128 + i / (DK / 4);
+  if (blockIdx.x * (NW * 32) >= len) {  // a tile of padded queries only: their rows are zero (ragged batches)
+    for (int i = tid; i < NW * 32 * (DK / 4); i += NW * 64) {
+      const int q = blockIdx.x * (NW * 32) + i / (DK / 4);
       if (q < N) *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + (i % (DK / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
   const int nchunks = (len + 31) / 32;
   for (int kc = 0; kc < nchunks; ++kc) {
     __syncthreads();
-    for (int i = tid; i < 32 * (DK / 4); i += 256) {
+    for (int i = tid; i < 32 * (DK / 4); i += NW * 64) {
       const int r = i / (DK / 4), c4 = i % (DK / 4);
       const int key = kc * 32 + r;
       float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
@@ -351,12 +354,25 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
   const float temperature = (float)sqrt((double)dk);
   dim3 grid((N + 127) / 128, n_head, B);
   if (x3) {
+    static const int nw = getenv("E2ETTS_ATT_NW") ? atoi(getenv("E2ETTS_ATT_NW")) : 8;  // tuning aid
+    if (nw == 8) {
+      dim3 g8((N + 255) / 256, n_head, B);
+      switch (dk) {
+        case 32: hipLaunchKernelGGL((attention_x3_kernel<32, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
+        case 64: hipLaunchKernelGGL((attention_x3_kernel<64, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
+        case 96: hipLaunchKernelGGL((attention_x3_kernel<96, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
+        case 128: hipLaunchKernelGGL((attention_x3_kernel<128, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
+        case 192: hipLaunchKernelGGL((attention_x3_kernel<192, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
+        default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
+      }
+      return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
+    }
     switch (dk) {
-      case 32: hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 64: hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 96: hipLaunchKernelGGL(attention_x3_kernel<96>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 128: hipLaunchKernelGGL(attention_x3_kernel<128>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 192: hipLaunchKernelGGL(attention_x3_kernel<192>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 32: hipLaunchKernelGGL((attention_x3_kernel<32, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 64: hipLaunchKernelGGL((attention_x3_kernel<64, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 96: hipLaunchKernelGGL((attention_x3_kernel<96, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 128: hipLaunchKernelGGL((attention_x3_kernel<128, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 192: hipLaunchKernelGGL((attention_x3_kernel<192, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
       default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
     }
     return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";

@@ -226,9 +226,9 @@ def main():
         peak = PEAK_BF16_TFLOPS / 3.0 if x3 else PEAK_FP32_TFLOPS
         roofline = {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 3), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "peak_note": ("bf16 dense MFMA peak 2500 / 3 MFMAs per split-precision product (nominal, at 2.4 GHz; under bf16 MFMA "
-                                  "load on random data the chip holds 1.8-1.9 GHz: MI355X_MICROARCH.md measures 1247-1483 TFLOP/s "
-                                  "for bare bf16 MFMA loops = 416-494 here)" if x3 else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                    "peak_note": ("bf16 dense MFMA peak 2500 / 3 MFMAs per split-precision product (nominal = what the chip does on zeros; a bare "
+                                  "MFMA loop on random operands measures 1724-1763 TFLOP/s at 1.65 GHz on this pool = 575-588 here: "
+                                  "profiles/r1/mfma_peak.txt)" if x3 else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                     "launches_per_step": dom["launches"] / args.steps,

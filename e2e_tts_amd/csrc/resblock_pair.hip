@@ -51,7 +51,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 }
 
 template <int BMI, int C, int WM, int WN, bool SPLIT, bool ACCUM>
-__global__ __launch_bounds__(256, 2) void resblock_pair_kernel(const PairParams p, const int tiles_per_block) {
+__global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(const PairParams p, const int tiles_per_block) {
   constexpr int NCH = C / 32;                  // 32-channel chunks (K of both convs, and N tiles of the intermediate)
   constexpr int NWN = C / WN;
   constexpr int MT = WM / 32, NT = WN / 32;

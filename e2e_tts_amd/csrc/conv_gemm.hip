@@ -160,6 +160,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   const int ntile32 = (p.Cout + 31) / 32;
   const __amdgpu_buffer_rsrc_t wf_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(BFRAG ? p.wfrag : p.w), 0, BFRAG ? (int)((long long)ntile32 * p.KW * nchunk * 4096) : 16, 0x00020000);
+  // structural zeros of the polyphase upsampler: this wave's columns lie in one half -> one of the three taps contributes nothing
+  int skip_tap = -1;
+  if (BFRAG && p.zero_tap_split > 0) {
+    const int c0 = n0 + wn * WN;
+    if (c0 + WN <= p.zero_tap_split) skip_tap = 2;
+    else if (c0 >= p.zero_tap_split) skip_tap = 0;
+  }
   int fnt[NT];  // this wave's 32-column tiles (clamped: columns beyond Cout are never stored)
 #pragma unroll
   for (int n = 0; n < NT; ++n) fnt[n] = min((n0 + wn * WN) / 32 + n, ntile32 - 1);
@@ -422,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
       // lane (row li, half lh) holds k = 16 s + 8 lh .. + 7 of its row: one 16-byte read per operand half
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
+        if (!BFRAG || j != skip_tap) {  // wave-uniform; the fragment path has no barrier per tap, so a wave may run ahead
         bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -448,6 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
             }
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
           }
+        }
         if constexpr (BFRAG) {  // fragments of this k-step are consumed: request them for the next iteration (one k-step of cover)
           // unconditional (the very last iteration re-requests fragments nobody uses): with a branch around them
           // hipcc has to assume "first k-step requested, second not" and waits for all eight loads at the loop head
@@ -568,6 +577,7 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   if (p.dil * (p.KW - 1) > MAX_HALO) return "conv_gemm: dilation * (KW - 1) exceeds the slab halo limit";
   if (p.pad < 0 || p.pad > p.dil * (p.KW - 1)) return "conv_gemm: pad out of range";
   if (p.out_div != 1.0f && !p.accumulate) return "conv_gemm: out_div needs accumulate (it closes a sum of branches)";
+  if (p.zero_tap_split != 0 && (p.KW != 3 || p.zero_tap_split < 0 || p.zero_tap_split >= p.Cout)) return "conv_gemm: zero_tap_split needs KW == 3 and 0 < split < Cout";
   if (p.x3 < 0 || p.x3 > 2) return "conv_gemm: x3 must be 0 (fp32), 1 (bf16x3) or 2 (bf16)";
   if (p.in_slope < 0.f || p.in_slope > 1.f) return "conv_gemm: in_slope must lie in [0, 1]";
   if ((long long)p.T * p.in_ld * 4 >= (1LL << 31) || (long long)p.Cout * p.KW * ((p.Cin + 31) / 32 * 32) * 4 >= (1LL << 31))

@@ -829,6 +829,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     p = ConvParams();
     p.B = B; p.T = (int)n; p.act_rows = act_stage[i]; p.in = S; setw(p, e->voc_up[i]); p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
     p.KW = 3; p.pad = 1; p.in_slope = 0.1f;
+    p.zero_tap_split = s * co / 2;  // phases < s/2 never use tap 2, the others never tap 0 (packer.polyphase_upsampler)
     RET(conv(e, p, 2.0 / 3.0));
     n *= s;
     ch = co;

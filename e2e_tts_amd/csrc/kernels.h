@@ -15,6 +15,8 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3 };
 struct ConvParams {
   const float* in = nullptr;     // [B, T, Cin]  (row stride in_ld, batch stride in_bs)
   const float* w = nullptr;      // [Cout, KW*Cin] tap-major fp32; x3: [Cout, KW, ceil(Cin/32), 32 bf16 hi | 32 bf16 lo]
+  int zero_tap_split = 0;        // polyphase upsampler (KW == 3): columns < split have an all-zero tap 2, columns >= split an all-zero
+                                 // tap 0 (packer.polyphase_upsampler); the fragment path skips those MFMAs.  0: no structural zeros
   const float* wfrag = nullptr;  // x3 only, optional: the same weights in MFMA-fragment order (launch_x3_to_frag); when set,
                                  // each wave loads its B fragments straight from global / L2 and the weight tile skips LDS
   int x3 = 0;                    // 1: split-precision bf16x3 MFMA path (w pre-split by the packer); 2: plain bf16 (hi x hi only)

@@ -280,3 +280,29 @@ def test_istft_vocoder_matches_reference(tag):
     eng = v._ensure_engine()
     with pytest.raises(ValueError):  # streaming is a HiFi-GAN-tail feature
         next(eng.vocoder_stream(iter([np.zeros((1, 4, 80), np.float32)]), 1))
+
+
+def test_full_size_batch_is_deterministic_and_linear_in_batch():
+    """Size-independent properties at the bench size (B = 32, L = 128 -> T = 768, default model): two runs give the same bits, and
+    an utterance's PCM does not depend on WHICH other utterances share the (equally long) batch -- rows are independent."""
+    from e2e_tts_amd import synth_weights as sw
+    from e2e_tts_amd.runtime import engine_from_states
+    cfg = cfgmod.default_config()
+    ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=1234, mode="fixed", frames_per_phoneme=6)
+    voc = sw.make_vocoder_state(cfg, seed=4321)
+    eng = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)
+    rng = np.random.Generator(np.random.PCG64(99))
+    B, L = 32, 128
+    ids = rng.integers(4, 131, size=(B, L)).astype(np.int64)
+    lens = np.full((B,), L, np.int64)
+    spk = np.array([1], np.int64)
+    a, ml, T = eng.synthesize(ids, lens, spk)
+    b, ml2, T2 = eng.synthesize(ids, lens, spk)
+    assert T == T2 == 768 and (ml == 768).all()
+    np.testing.assert_array_equal(a, b)
+    perm = rng.permutation(B)
+    c, _, _ = eng.synthesize(np.ascontiguousarray(ids[perm]), lens, spk)
+    np.testing.assert_array_equal(c, a[perm])
+    half, _, _ = eng.synthesize(np.ascontiguousarray(ids[:5]), lens[:5], spk)
+    np.testing.assert_array_equal(half, a[:5])
+    assert np.abs(a.astype(np.int32)).max() > 100  # not silence

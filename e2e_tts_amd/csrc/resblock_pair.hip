@@ -131,18 +131,20 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
 
   // ---- weight fragments: B operand of one k-step, one 1 KiB load per (32-column tile, hi | lo)
   float4 bfr[2][NT][2];
+  auto load_frag_n = [&](int conv, int chunk, int j, int ks, int n) {
+#pragma unroll
+    for (int hl = 0; hl < (SPLIT ? 2 : 1); ++hl) {
+      const int nt = wn * NT + n;
+      const int soff = (conv * frag_words + (((((nt * KW + j) * NCH + chunk) * 2 + ks) * 2 + hl) << 8)) * 4;
+      bfr[ks][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
+    }
+  };
   auto load_frag = [&](int conv, int chunk, int j, int ks) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int hl = 0; hl < (SPLIT ? 2 : 1); ++hl) {
-        const int nt = wn * NT + n;
-        const int soff = (conv * frag_words + (((((nt * KW + j) * NCH + chunk) * 2 + ks) * 2 + hl) << 8)) * 4;
-        bfr[ks][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
-      }
+    for (int n = 0; n < NT; ++n) load_frag_n(conv, chunk, j, ks, n);
   };
-  // one tap of one chunk: 2 k-steps of 16, the fragments of k-step ks are re-requested for the next iteration (nconv, nchunk, nj)
-  // as soon as its MFMAs have been issued
+  // one tap of one chunk: 2 k-steps of 16.  Column tiles outermost: the fragments of a column tile are re-requested for the next
+  // iteration (nconv, nchunk, nj) as soon as ITS MFMAs have been issued, the other column tile's MFMAs are extra cover
   auto mma_tap = [&](const float* a_base, int nconv, int nchunk, int nj) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -153,9 +155,9 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
         if constexpr (SPLIT) al[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + 16 + ks * 8));
       }
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int n = 0; n < NT; ++n) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
+        for (int m = 0; m < MT; ++m) {
           const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[ks][n][0]);
           if constexpr (SPLIT) {
             const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[ks][n][1]);
@@ -164,11 +166,12 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
           }
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
         }
-      // keep the request right behind the MFMAs that free its registers (left alone, hipcc sinks all requests to the end
-      // of the iteration, a few cycles before the next one waits for them)
-      __builtin_amdgcn_sched_barrier(0);
-      load_frag(nconv, nchunk, nj, ks);
-      __builtin_amdgcn_sched_barrier(0);
+        // keep the request right behind the MFMAs that free its registers (left alone, hipcc sinks all requests to the end
+        // of the iteration, a few cycles before the next one waits for them)
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag_n(nconv, nchunk, nj, ks, n);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 

@@ -23,6 +23,7 @@
 // being complete -- overwritten by the intermediate [C/32][(BMI + KW - 1) x 36 words], then by the epilogue's transpose
 // patches.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -336,8 +337,9 @@ const char* launch_pair_cfg(const PairParams& p, hipStream_t s) {
   if (lds > 80 * 1024) return "resblock_pair: LDS region exceeds 80 KiB";
   const int mtiles = (p.T + BMO - 1) / BMO;
   const long long total = (long long)mtiles * p.B;
-  int tpb = (int)(total / (256 * 8));
-  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  static const int wg_per_cu = getenv("E2ETTS_PAIR_WG_PER_CU") ? atoi(getenv("E2ETTS_PAIR_WG_PER_CU")) : 64;  // tuning aid; measured: 8 -> 53.4, 16 -> 52.3, 32..64 -> 51.9-52.0 ms/step (one tile per workgroup balances best)
+  int tpb = (int)(total / (256 * wg_per_cu));
+  tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
   if (tpb > mtiles) tpb = mtiles;
   dim3 grid((mtiles + tpb - 1) / tpb, p.B);
   if (p.accumulate)

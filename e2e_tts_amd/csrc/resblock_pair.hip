@@ -76,7 +76,11 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
   const int b = blockIdx.y;
   const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
   const int mtiles = (t_act + BMO - 1) / BMO;
-  const int tile0 = blockIdx.x * tiles_per_block;
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive block ids would put
+  // neighbouring tiles -- which share (KW-1)(d+1) halo rows -- on different L2s.  The grid is a multiple of 8 wide; block x works
+  // on tile run (x % 8) * (gridDim.x / 8) + x / 8: each XCD walks a contiguous eighth of the utterance.
+  const int run = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tile0 = run * tiles_per_block;
   const int ntile = min(tiles_per_block, mtiles - tile0);
   if (ntile <= 0) return;
 
@@ -341,7 +345,7 @@ const char* launch_pair_cfg(const PairParams& p, hipStream_t s) {
   int tpb = (int)(total / (256 * wg_per_cu));
   tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
   if (tpb > mtiles) tpb = mtiles;
-  dim3 grid((mtiles + tpb - 1) / tpb, p.B);
+  dim3 grid(((mtiles + tpb - 1) / tpb + 7) / 8 * 8, p.B);  // a multiple of 8 (see the XCD-aware order in the kernel); extra blocks exit
   if (p.accumulate)
     hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, true>), grid, dim3(256), lds, s, p, tpb);
   else

@@ -23,7 +23,6 @@
 // being complete -- overwritten by the intermediate [C/32][(BMI + KW - 1) x 36 words], then by the epilogue's transpose
 // patches.
 #include <algorithm>
-#include <cstdlib>
 
 #include "kernels.h"
 
@@ -52,7 +51,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 }
 
 template <int BMI, int C, int WM, int WN, bool SPLIT, bool ACCUM>
-__global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(const PairParams p, const int tiles_per_block) {
+__global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(const PairParams p) {
   constexpr int NCH = C / 32;                  // 32-channel chunks (K of both convs, and N tiles of the intermediate)
   constexpr int NWN = C / WN;
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -79,10 +78,10 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
   // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive block ids would put
   // neighbouring tiles -- which share (KW-1)(d+1) halo rows -- on different L2s.  The grid is a multiple of 8 wide; block x works
   // on tile run (x % 8) * (gridDim.x / 8) + x / 8: each XCD walks a contiguous eighth of the utterance.
-  const int run = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int tile0 = run * tiles_per_block;
-  const int ntile = min(tiles_per_block, mtiles - tile0);
-  if (ntile <= 0) return;
+  // One tile per workgroup: many short workgroups balance better than a few persistent ones (measured: 8 workgroups per CU walking 6
+  // tiles each 53.4 ms/step, one tile each 51.9), and the partner workgroup on the CU covers this one's staging and epilogues.
+  const int tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (tile >= mtiles) return;
 
   const float* x_b = p.x + (long long)b * p.x_bs;
   float* out_b = p.out + (long long)b * p.out_bs;
@@ -275,61 +274,48 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
   };
 
   // ---- main
-  load_a(tile0, 0);
+  load_a(tile, 0);
   store_a();
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) load_frag(0, 0, 0, ks);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing in flight at the loop heads: their waits stay counted (see conv_gemm.hip)
 
-  for (int tl = 0; tl < ntile; ++tl) {
-    const int tile = tile0 + tl;
-    const bool more = tl + 1 < ntile;
-    // conv1: K = chunks of x, slab re-staged per chunk
-    for (int c = 0; c < NCH; ++c) {
-      if (c + 1 < NCH) load_a(tile, c + 1);
-      __syncthreads();  // slab of chunk c visible
-      const float* a0 = smem + (wm * WM + li) * LDK + lh * 4;
-      for (int j = 0; j < KW; ++j) {
-        const bool lastj = j + 1 == KW;
-        const bool lastc = c + 1 == NCH;
-        // next iteration in fragment order: next tap; else tap 0 of the next chunk; else conv2's first
-        const int nconv = (lastj && lastc) ? 1 : 0;
-        const int nchunk = lastj ? (lastc ? 0 : c + 1) : c;
-        const int nj = lastj ? 0 : j + 1;
-        mma_tap(a0 + j * dil * LDK, nconv, nchunk, nj);
-      }
-      if (c + 1 < NCH) {
-        __syncthreads();  // every wave is done with the slab of chunk c
-        store_a();
-      }
+  // conv1: K = chunks of x, slab re-staged per chunk
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) load_a(tile, c + 1);
+    __syncthreads();  // slab of chunk c visible
+    const float* a0 = smem + (wm * WM + li) * LDK + lh * 4;
+    for (int j = 0; j < KW; ++j) {
+      const bool lastj = j + 1 == KW;
+      const bool lastc = c + 1 == NCH;
+      // next iteration in fragment order: next tap; else tap 0 of the next chunk; else conv2's first
+      const int nconv = (lastj && lastc) ? 1 : 0;
+      const int nchunk = lastj ? (lastc ? 0 : c + 1) : c;
+      const int nj = lastj ? 0 : j + 1;
+      mma_tap(a0 + j * dil * LDK, nconv, nchunk, nj);
     }
-    __syncthreads();  // x slab dead
-    epilogue1(tile);
-    // next tile's first slab flies behind conv2 -- except in the accumulate form at >= 64 channels, whose epilogue needs the
-    // registers for the rows it adds to (with both, hipcc spilled 50+ VGPRs and the launch ran 25-50 % longer)
-    constexpr bool EARLY_SLAB = !(ACCUM && C >= 64);
-    if (EARLY_SLAB && more) load_a(tile + 1, 0);
-    __syncthreads();  // intermediate visible
-    // conv2: K = chunks of the intermediate, dilation 1
-    for (int c = 0; c < NCH; ++c) {
-      const float* a0 = smem + (c * irows + wm * WM + li) * LDK + lh * 4;
-      for (int j = 0; j < KW; ++j) {
-        const bool lastj = j + 1 == KW;
-        const bool lastc = c + 1 == NCH;
-        const int nconv = (lastj && lastc) ? 0 : 1;  // after the last tap: conv1 of the next tile (same weights)
-        const int nchunk = lastj ? (lastc ? 0 : c + 1) : c;
-        const int nj = lastj ? 0 : j + 1;
-        mma_tap(a0 + j * LDK, nconv, nchunk, nj);
-      }
-    }
-    __syncthreads();  // intermediate dead: the region now carries the transpose patches
-    epilogue2(tile);
-    if (more) {
-      if (!EARLY_SLAB) load_a(tile + 1, 0);
-      __syncthreads();  // patches read back
+    if (c + 1 < NCH) {
+      __syncthreads();  // every wave is done with the slab of chunk c
       store_a();
     }
   }
+  __syncthreads();  // x slab dead
+  epilogue1(tile);
+  __syncthreads();  // intermediate visible
+  // conv2: K = chunks of the intermediate, dilation 1
+  for (int c = 0; c < NCH; ++c) {
+    const float* a0 = smem + (c * irows + wm * WM + li) * LDK + lh * 4;
+    for (int j = 0; j < KW; ++j) {
+      const bool lastj = j + 1 == KW;
+      const bool lastc = c + 1 == NCH;
+      const int nconv = 1;  // (the requests behind the very last tap re-read conv2's first fragments: nobody uses them)
+      const int nchunk = lastj ? (lastc ? 0 : c + 1) : c;
+      const int nj = lastj ? 0 : j + 1;
+      mma_tap(a0 + j * LDK, nconv, nchunk, nj);
+    }
+  }
+  __syncthreads();  // intermediate dead: the region now carries the transpose patches
+  epilogue2(tile);
 }
 
 template <int BMI, int C, int WM, int WN, bool SPLIT>
@@ -340,16 +326,11 @@ const char* launch_pair_cfg(const PairParams& p, hipStream_t s) {
   const size_t lds = words * sizeof(float);
   if (lds > 80 * 1024) return "resblock_pair: LDS region exceeds 80 KiB";
   const int mtiles = (p.T + BMO - 1) / BMO;
-  const long long total = (long long)mtiles * p.B;
-  static const int wg_per_cu = getenv("E2ETTS_PAIR_WG_PER_CU") ? atoi(getenv("E2ETTS_PAIR_WG_PER_CU")) : 64;  // tuning aid; measured: 8 -> 53.4, 16 -> 52.3, 32..64 -> 51.9-52.0 ms/step (one tile per workgroup balances best)
-  int tpb = (int)(total / (256 * wg_per_cu));
-  tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
-  if (tpb > mtiles) tpb = mtiles;
-  dim3 grid(((mtiles + tpb - 1) / tpb + 7) / 8 * 8, p.B);  // a multiple of 8 (see the XCD-aware order in the kernel); extra blocks exit
+  dim3 grid((mtiles + 7) / 8 * 8, p.B);  // a multiple of 8 (see the XCD-aware order in the kernel); extra blocks exit
   if (p.accumulate)
-    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, true>), grid, dim3(256), lds, s, p, tpb);
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, true>), grid, dim3(256), lds, s, p);
   else
-    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, false>), grid, dim3(256), lds, s, p, tpb);
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, false>), grid, dim3(256), lds, s, p);
   return hipGetLastError() == hipSuccess ? nullptr : "resblock_pair: launch failed";
 }
 

@@ -23,6 +23,7 @@
 // being complete -- overwritten by the intermediate [C/32][(BMI + KW - 1) x 36 words], then by the epilogue's transpose
 // patches.
 #include <algorithm>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -134,22 +135,35 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
   };
 
   // ---- weight fragments: B operand of one k-step, one 1 KiB load per (32-column tile, hi | lo)
-  float4 bfr[2][NT][2];
-  auto load_frag_n = [&](int conv, int chunk, int j, int ks, int n) {
+  // DEEP (32 channels: 12 MFMAs per tap are far less than an L2 round trip, and registers are plentiful): the fragments of the next tap
+  // are requested one whole tap ahead into the other of two buffers.  Which buffer a tap reads is a compile-time parity; taps
+  // alternate, a run has an odd number of taps, so conv1 starts at parity 0 and conv2 at parity 1.
+  constexpr bool DEEP = C == 32;
+  float4 bfr[DEEP ? 2 : 1][2][NT][2];
+  auto load_frag_n = [&](auto par, int conv, int chunk, int j, int ks, int n) {
+    constexpr int P = decltype(par)::value;
 #pragma unroll
     for (int hl = 0; hl < (SPLIT ? 2 : 1); ++hl) {
       const int nt = wn * NT + n;
       const int soff = (conv * frag_words + (((((nt * KW + j) * NCH + chunk) * 2 + ks) * 2 + hl) << 8)) * 4;
-      bfr[ks][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
+      bfr[P][ks][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
     }
   };
   auto load_frag = [&](int conv, int chunk, int j, int ks) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) load_frag_n(conv, chunk, j, ks, n);
+    for (int n = 0; n < NT; ++n) load_frag_n(std::integral_constant<int, 0>{}, conv, chunk, j, ks, n);
   };
-  // one tap of one chunk: 2 k-steps of 16.  Column tiles outermost: the fragments of a column tile are re-requested for the next
-  // iteration (nconv, nchunk, nj) as soon as ITS MFMAs have been issued, the other column tile's MFMAs are extra cover
-  auto mma_tap = [&](const float* a_base, int nconv, int nchunk, int nj) {
+  // one tap of one chunk: 2 k-steps of 16.  par: the buffer this tap reads (DEEP), else 0.  Column tiles outermost: without DEEP the
+  // fragments of a column tile are re-requested for the next iteration (nconv, nchunk, nj) as soon as ITS MFMAs have been issued
+  auto mma_tap = [&](auto par, const float* a_base, int nconv, int nchunk, int nj) {
+    constexpr int P = decltype(par)::value;
+    if constexpr (DEEP) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) load_frag_n(std::integral_constant<int, 1 - P>{}, nconv, nchunk, nj, ks, n);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[MT], al[MT];
@@ -162,21 +176,35 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
       for (int n = 0; n < NT; ++n) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[ks][n][0]);
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[P][ks][n][0]);
           if constexpr (SPLIT) {
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[ks][n][1]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[P][ks][n][1]);
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][n], 0, 0, 0);
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
           }
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
         }
-        // keep the request right behind the MFMAs that free its registers (left alone, hipcc sinks all requests to the end
-        // of the iteration, a few cycles before the next one waits for them)
-        __builtin_amdgcn_sched_barrier(0);
-        load_frag_n(nconv, nchunk, nj, ks, n);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!DEEP) {
+          // keep the request right behind the MFMAs that free its registers (left alone, hipcc sinks all requests to the end
+          // of the iteration, a few cycles before the next one waits for them)
+          __builtin_amdgcn_sched_barrier(0);
+          load_frag_n(std::integral_constant<int, 0>{}, nconv, nchunk, nj, ks, n);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
+  };
+  // the KW taps of one (conv, chunk) run, KW odd.  par0: parity of its first tap (DEEP).  After the last tap the fragment order continues
+  // with (nconv_end, nchunk_end, tap 0)
+  auto run_taps = [&](auto par0, const float* a0, int row_step, int conv, int c, int nconv_end, int nchunk_end) {
+    constexpr int P0 = DEEP ? decltype(par0)::value : 0;
+    constexpr int P1 = DEEP ? 1 - P0 : 0;
+    int j = 0;
+    for (; j + 2 < KW; j += 2) {
+      mma_tap(std::integral_constant<int, P0>{}, a0 + j * row_step, conv, c, j + 1);
+      mma_tap(std::integral_constant<int, P1>{}, a0 + (j + 1) * row_step, conv, c, j + 2);
+    }
+    mma_tap(std::integral_constant<int, P0>{}, a0 + j * row_step, nconv_end, nchunk_end, 0);  // j == KW - 1
   };
 
   // ---- epilogue 1: intermediate = lrelu(acc + b1) (zero outside [0, T)), split, into LDS as conv2's A operand
@@ -284,16 +312,9 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
   for (int c = 0; c < NCH; ++c) {
     if (c + 1 < NCH) load_a(tile, c + 1);
     __syncthreads();  // slab of chunk c visible
-    const float* a0 = smem + (wm * WM + li) * LDK + lh * 4;
-    for (int j = 0; j < KW; ++j) {
-      const bool lastj = j + 1 == KW;
-      const bool lastc = c + 1 == NCH;
-      // next iteration in fragment order: next tap; else tap 0 of the next chunk; else conv2's first
-      const int nconv = (lastj && lastc) ? 1 : 0;
-      const int nchunk = lastj ? (lastc ? 0 : c + 1) : c;
-      const int nj = lastj ? 0 : j + 1;
-      mma_tap(a0 + j * dil * LDK, nconv, nchunk, nj);
-    }
+    const bool lastc = c + 1 == NCH;
+    // DEEP implies NCH == 1, so the run's parity is known at compile time
+    run_taps(std::integral_constant<int, 0>{}, smem + (wm * WM + li) * LDK + lh * 4, dil * LDK, 0, c, lastc ? 1 : 0, lastc ? 0 : c + 1);
     if (c + 1 < NCH) {
       __syncthreads();  // every wave is done with the slab of chunk c
       store_a();
@@ -302,17 +323,10 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
   __syncthreads();  // x slab dead
   epilogue1(tile);
   __syncthreads();  // intermediate visible
-  // conv2: K = chunks of the intermediate, dilation 1
+  // conv2: K = chunks of the intermediate, dilation 1 (the requests behind its very last tap re-read its first fragments: unused)
   for (int c = 0; c < NCH; ++c) {
-    const float* a0 = smem + (c * irows + wm * WM + li) * LDK + lh * 4;
-    for (int j = 0; j < KW; ++j) {
-      const bool lastj = j + 1 == KW;
-      const bool lastc = c + 1 == NCH;
-      const int nconv = 1;  // (the requests behind the very last tap re-read conv2's first fragments: nobody uses them)
-      const int nchunk = lastj ? (lastc ? 0 : c + 1) : c;
-      const int nj = lastj ? 0 : j + 1;
-      mma_tap(a0 + j * LDK, nconv, nchunk, nj);
-    }
+    const bool lastc = c + 1 == NCH;
+    run_taps(std::integral_constant<int, 1>{}, smem + (c * irows + wm * WM + li) * LDK + lh * 4, LDK, 1, c, 1, lastc ? 0 : c + 1);
   }
   __syncthreads();  // intermediate dead: the region now carries the transpose patches
   epilogue2(tile);

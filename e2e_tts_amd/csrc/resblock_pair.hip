@@ -76,13 +76,15 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
   const int b = blockIdx.y;
   const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
   const int mtiles = (t_act + BMO - 1) / BMO;
-  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive block ids would put
-  // neighbouring tiles -- which share (KW-1)(d+1) halo rows -- on different L2s.  The grid is a multiple of 8 wide; block x works
-  // on tile run (x % 8) * (gridDim.x / 8) + x / 8: each XCD walks a contiguous eighth of the utterance.
   // One tile per workgroup: many short workgroups balance better than a few persistent ones (measured: 8 workgroups per CU walking 6
   // tiles each 53.4 ms/step, one tile each 51.9), and the partner workgroup on the CU covers this one's staging and epilogues.
-  const int tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  if (tile >= mtiles) return;
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive block ids would put
+  // neighbouring tiles -- which share (KW-1)(d+1) halo rows -- on different L2s.  Block x of an utterance's row of the grid (a
+  // multiple of 8 wide) works on tile (x % 8) * ceil(mtiles / 8) + x / 8: every XCD walks a contiguous eighth of the tiles THIS
+  // utterance really has (ragged batches), so all XCDs get the same share of every utterance.
+  const int eighth = (mtiles + 7) >> 3;
+  const int tile = (blockIdx.x & 7) * eighth + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= eighth || tile >= mtiles) return;
 
   const float* x_b = p.x + (long long)b * p.x_bs;
   float* out_b = p.out + (long long)b * p.out_bs;

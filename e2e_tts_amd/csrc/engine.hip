@@ -475,7 +475,9 @@ int bind_vocoder(e2etts_engine* e) {
 // Frames of mel context one output frame depends on, each side (conservative bound from the layer geometry: conv_post 3
 // samples, per stage the widest ResBlock1 sum_m ((k-1)/2 d_m + (k-1)/2), each upsampler +-2 input positions, conv_pre 3 frames).
 int vocoder_halo_frames(const e2etts_config& c) {
-  double r = 3.0;
+  // HiFi-GAN tail: conv_post reaches 3 samples.  iSTFTNet tail: conv_post 3 frames + the reflection pad's shift of 1 + the inverse
+  // STFT's overlap (a sample is the sum of n_fft / hop frames: n_fft / (2 hop) to either side), all at the trunk's output rate
+  double r = c.voc_istft_nfft ? 4.0 + (double)c.voc_istft_nfft / (2.0 * c.voc_istft_hop) : 3.0;
   for (int i = c.voc_stages - 1; i >= 0; --i) {
     int worst = 0;
     for (int j = 0; j < c.voc_n_kernels; ++j) {
@@ -781,10 +783,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   const bool istft = c.voc_istft_nfft != 0;
   const long long nsamp = istft ? len * c.voc_istft_hop : len;
   if (nsamp != (long long)T * c.hop_length) return e->fail(E2ETTS_EINVAL, "upsample product != hop_length");
-  if (istft) {
-    if (ragged_lens) return e->fail(E2ETTS_EINVAL, "ragged compute is not implemented for the iSTFT vocoder");
-    maxv += ch;  // the reflection-padded frame
-  }
+  if (istft) maxv += ch;  // the reflection-padded frame (the tail itself is always computed in full: it is 18 channels wide)
   const size_t vb = (size_t)B * maxv * 4;
   RET(ensure(e, e->v0, vb));
   RET(ensure(e, e->v1, vb));
@@ -1144,7 +1143,7 @@ int e2etts_synthesize(e2etts_engine* e, const int64_t* ids, const int64_t* lens,
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(e, hipSetDevice(e->device));
   if (B > 4096) return e->fail(E2ETTS_EINVAL, "B > 4096");
-  const bool ragged = e->ragged != 0 && !e->cfg.voc_istft_nfft;
+  const bool ragged = e->ragged != 0;
   RET(acoustic_impl(e, ids, lens, B, L, speaker, n_spk_ids, d_control, p_control, e_control, ragged));
   if (T_out) *T_out = e->last_T;
   RET(vocoder_impl(e, ptr<float>(e->melpost), B, e->last_T, false, true, ragged ? ptr<int32_t>(e->mel32) : nullptr));
@@ -1190,7 +1189,6 @@ int e2etts_vocoder_stream_begin(e2etts_engine* e, int B) {
   std::lock_guard<std::mutex> lk(e->mu);
   if (!e->voc_loaded) return e->fail(E2ETTS_ESTATE, "vocoder weights not loaded");
   if (B <= 0 || B > 4096) return e->fail(E2ETTS_EINVAL, "B out of range");
-  if (e->cfg.voc_istft_nfft) return e->fail(E2ETTS_EINVAL, "the streaming vocoder is not implemented for the iSTFT generator");
   e->st_B = B;
   e->st_carry_n = 0;
   e->st_emitted = 0;

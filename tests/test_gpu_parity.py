@@ -277,9 +277,47 @@ def test_istft_vocoder_matches_reference(tag):
         assert mean_l1(spec.cpu().numpy(), g[f"{tag}.spec"]) < bar * 10, prec
         assert mean_l1(phase.cpu().numpy(), g[f"{tag}.phase"]) < bar * 10, prec
         assert mean_l1(wav.cpu().numpy(), g[f"{tag}.wav"]) < bar, prec
+    # streaming: chunked pushes concatenate to the one-shot waveform bit for bit (the reflection pad and the overlap-add edges of a
+    # window fall into its discarded context)
     eng = v._ensure_engine()
-    with pytest.raises(ValueError):  # streaming is a HiFi-GAN-tail feature
-        next(eng.vocoder_stream(iter([np.zeros((1, 4, 80), np.float32)]), 1))
+    eng.set_precision("bf16x3")
+    rng = np.random.Generator(np.random.PCG64(17))
+    T = 61
+    m2 = rng.standard_normal((2, T, 80)).astype(np.float32)
+    whole, _ = eng.vocoder(m2, 2, T, channels_first=False)
+    for sizes in ([T], [1, 7, 20, 3, 30], [16, 16, 16, 13]):
+        pos, chunks = 0, []
+        for n in sizes:
+            chunks.append(np.ascontiguousarray(m2[:, pos:pos + n]))
+            pos += n
+        out = np.concatenate(list(eng.vocoder_stream(chunks, 2)), axis=1)
+        np.testing.assert_array_equal(out, whole)
+
+
+def test_istft_engine_end_to_end_ragged():
+    """Acoustic model + iSTFTNet vocoder in one engine: synthesize() with ragged compute gives the padded run's PCM on every valid sample."""
+    from e2e_tts_amd import packer, synth_weights as sw
+    from e2e_tts_amd._lib import Engine
+    cfg = cfgmod.tiny_config()
+    dims = cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4, vocoder="istft")
+    ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=21, mode="varied")
+    voc = sw.make_vocoder_state(cfg, seed=22, vocoder="istft")
+    eng = Engine(dims, 0)
+    eng.load_weights(packer.pack(dims, ac, voc))
+    rng = np.random.Generator(np.random.PCG64(23))
+    lens = np.array([30, 11, 22, 5], np.int64)
+    ids = np.zeros((4, 30), np.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(4, 131, size=n)
+    spk = np.array([2], np.int64)
+    eng.set_ragged(False)
+    full, ml, T = eng.synthesize(ids, lens, spk)
+    eng.set_ragged(True)
+    rag, ml2, T2 = eng.synthesize(ids, lens, spk)
+    assert T == T2 and (ml == ml2).all() and ml.max() == T and ml.min() < T
+    for b, n in enumerate(ml * 256):
+        np.testing.assert_array_equal(rag[b, :n], full[b, :n])
+    assert np.abs(full.astype(np.int32)).max() > 10
 
 
 def test_full_size_batch_is_deterministic_and_linear_in_batch():

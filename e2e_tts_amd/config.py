@@ -43,6 +43,17 @@ _DEFAULT = {
                     "encoder_dropout": 0.1,
                     "decoder_dropout": 0.1,
                 },
+                # reference config/model_config.yaml:16-24 (selected by block_type: "conformer", U/model.py:26-27)
+                "conformer": {
+                    "encoder_head": 8,
+                    "decoder_head": 8,
+                    "ffn_expansion_factor": 4,
+                    "conv_kernel_size": 31,
+                    "conv_expansion_factor": 2,
+                    "half_step_residual": True,
+                    "encoder_dropout": 0.1,
+                    "decoder_dropout": 0.1,
+                },
             },
             "variance": {
                 "duration_modelling": {
@@ -128,6 +139,7 @@ def tiny_config() -> dict:
     fs["encoder_hidden"] = 64
     fs["decoder_hidden"] = 64
     fs["building_block"]["transformer"]["conv_filter_size"] = 96
+    fs["building_block"]["conformer"].update(encoder_head=4, decoder_head=4, conv_kernel_size=7)
     fs["variance"]["variance_predictor"]["filter_size"] = 48
     fs["postnet"]["embedding_dim"] = 48
     c["models"]["hifigan"]["upsample_initial_channel"] = 64
@@ -181,6 +193,7 @@ class CEngineConfig(ctypes.Structure):
         ("voc_resblock", ctypes.c_int32),
         ("voc_istft_nfft", ctypes.c_int32),
         ("voc_istft_hop", ctypes.c_int32),
+        ("block_type", ctypes.c_int32),
     ]
 
 
@@ -220,6 +233,9 @@ class EngineDims:
     voc_resblock: int = 1     # 1: ResBlock1, 2: ResBlock2 (reference V/layers.py)
     voc_istft_nfft: int = 0   # 0: HiFi-GAN tail; else iSTFTNet (reference V/generator.py:65-113)
     voc_istft_hop: int = 0
+    cf_ffn_factor: float = 0.5  # Conformer half_step_residual (U/blocks/conformer.py:209-212); folded into the weights by the packer
+    block_type: int = 0       # 0: FFT block (U/blocks/transformer.py), 1: Conformer block (U/blocks/conformer.py); then ffn_dim =
+                              # hidden x ffn_expansion_factor and ffn_k1 = the depthwise kernel size
 
     @property
     def upsample_total(self) -> int:
@@ -244,6 +260,7 @@ class EngineDims:
         c.f0_mean = float(self.f0_mean)
         c.f0_std = float(self.f0_std)
         c.voc_resblock, c.voc_istft_nfft, c.voc_istft_hop = int(self.voc_resblock), int(self.voc_istft_nfft), int(self.voc_istft_hop)
+        c.block_type = int(self.block_type)
         if len(self.voc_up_rate) > MAX_STAGES or len(self.voc_rb_kernel) > MAX_RESBLOCK_KERNELS:
             raise ValueError("vocoder config exceeds the C-ABI limits")
         c.voc_stages = len(self.voc_up_rate)
@@ -274,11 +291,18 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         raise ValueError("vocoder must be 'hifigan' or 'istft'")
     hg = config["models"][vocoder]
     bt = fs["building_block"]["block_type"]
-    if bt != "transformer":
+    if bt not in ("transformer", "conformer"):
         raise NotImplementedError(
-            f"building_block.block_type={bt!r}: only the default 'transformer' FFT block is on the hot path "
+            f"building_block.block_type={bt!r}: only the 'transformer' FFT block and the 'conformer' block are implemented "
             "(reference U/model.py:24-33; SURVEY.md section 8(f))")
-    tr = fs["building_block"]["transformer"]
+    tr = fs["building_block"][bt]
+    if bt == "conformer":
+        # U/blocks/conformer.py:31-36: heads, FFN expansion, depthwise kernel; conv expansion is asserted to be 2 there (:466)
+        if tr["conv_expansion_factor"] != 2:
+            raise NotImplementedError("conv_expansion_factor must be 2 (reference U/blocks/conformer.py:466)")
+        if tr["conv_kernel_size"] % 2 != 1:
+            raise ValueError("conformer conv_kernel_size must be odd (reference U/blocks/conformer.py:465)")
+        tr = dict(tr, conv_filter_size=fs["encoder_hidden"] * tr["ffn_expansion_factor"], conv_kernel_size=[tr["conv_kernel_size"], 1])
     if tr["encoder_head"] != tr["decoder_head"]:
         raise NotImplementedError("encoder_head != decoder_head")
     if fs["encoder_hidden"] != fs["decoder_hidden"]:
@@ -329,6 +353,8 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         hop_length=hop, sample_rate=config["audio"]["signal"]["sampling_rate"],
         pos_table_rows=pos_table_rows,
         f0_mean=float(stats["f0"]["mean"]), f0_std=float(stats["f0"]["std"]),
+        block_type=1 if bt == "conformer" else 0,
+        cf_ffn_factor=(0.5 if tr.get("half_step_residual", True) else 1.0),
     )
     if dims.ffn_k2 != 1:
         raise NotImplementedError("second FFN conv must be k=1")

@@ -150,6 +150,152 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+// ---- Conformer: relative-position attention (reference U/blocks/conformer.py:399-440), fp32.  Same flash-style structure and MFMA
+// orientation as attention_kernel; differences: u_bias is added to the query fragments; nothing is masked (the block calls the module
+// without a mask, :252, so padded keys take part and padded queries are computed); the score gets the shifted position term from the
+// materialised (q + v) . P matrix `ps` before it is divided by sqrt(d_model) (:384, :418).  DK need not be a multiple of 32: the
+// P . V product runs on ceil(DK / 32) tiles with V zero-padded in LDS.
+template <int DK>
+__global__ __launch_bounds__(256) void rel_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ ps, int ldp,
+                                                            const float* __restrict__ ub, float* __restrict__ out, int N, int H,
+                                                            float temperature) {
+  static_assert(DK % 8 == 0, "head dim must be a multiple of 8");
+  constexpr int DT = (DK + 31) / 32;
+  constexpr int LDS_LD = DT * 32 + 4;
+  constexpr int QQ = DK / 8;
+  __shared__ __attribute__((aligned(16))) float Ks[32 * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * LDS_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y, n_head = gridDim.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int ld = 3 * H;
+  const float* base = qkv + (long long)b * N * ld;
+  const float* qp = base + head * DK;
+  const float* kp = base + H + head * DK;
+  const float* vp = base + 2 * H + head * DK;
+  const float* psb = ps + ((long long)b * n_head + head) * N * ldp;
+
+  const int qi = min(q0 + li, N - 1);  // this lane's query (clamped: rows >= N are computed and dropped)
+  float4 qf[QQ];
+  {
+    const float* qr = qp + (long long)qi * ld + lh * 4;
+    const float* ur = ub + head * DK + lh * 4;
+#pragma unroll
+    for (int qq = 0; qq < QQ; ++qq) {
+      const float4 a = *reinterpret_cast<const float4*>(qr + qq * 8), u4 = *reinterpret_cast<const float4*>(ur + qq * 8);
+      qf[qq] = make_float4(a.x + u4.x, a.y + u4.y, a.z + u4.z, a.w + u4.w);
+    }
+  }
+  // zero the V padding columns once (they are never overwritten)
+  if (DK % 32) {
+    for (int i = tid; i < 32 * (DT * 32 - DK); i += 256) {
+      const int r = i / (DT * 32 - DK), c = DK + i % (DT * 32 - DK);
+      Vs[r * LDS_LD + c] = 0.f;
+    }
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nchunks = (N + 31) / 32;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    __syncthreads();
+    for (int i = tid; i < 32 * (DK / 4); i += 256) {
+      const int r = i / (DK / 4), c = (i % (DK / 4)) * 4;
+      const int key = kc * 32 + r;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (key < N) {
+        kv = *reinterpret_cast<const float4*>(kp + (long long)key * ld + c);
+        vv = *reinterpret_cast<const float4*>(vp + (long long)key * ld + c);
+      }
+      *reinterpret_cast<float4*>(Ks + r * LDS_LD + c) = kv;
+      *reinterpret_cast<float4*>(Vs + r * LDS_LD + c) = vv;
+    }
+    // shifted position term of this lane's 16 (query, key) pairs, requested before the MFMAs that hide its latency
+    float pterm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = 0.f;
+      if (j < N && j != qi + 1) {
+        const int row = j <= qi ? qi : qi + 1;
+        const int col = j <= qi ? N - 1 - qi + j : j - qi - 2;
+        v = psb[(long long)row * ldp + col];
+      }
+      pterm[r] = v;
+    }
+    __syncthreads();
+
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float* ka = Ks + li * LDS_LD + lh * 4;
+#pragma unroll
+    for (int qq = 0; qq < QQ; ++qq) {
+      const float4 a = *reinterpret_cast<const float4*>(ka + qq * 8);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[qq].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[qq].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[qq].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[qq].w, s, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = (s[r] + pterm[r]) / temperature;
+      v = key < N ? v : -INFINITY;
+      s[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);  // finite: every chunk has a key < N
+    const float corr = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = expf(s[r] - m_new);
+      s[r] = pv;
+      psum += pv;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float a = Vs[key * LDS_LD + d * 32 + li];
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  const int q = q0 + li;
+  if (q < N) {
+    const float inv = 1.0f / l_run;
+    float* orow = out + ((long long)b * N + q) * H + head * DK + 4 * lh;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (d * 32 + 8 * g + 4 * lh < DK) {
+          float4 v;
+          v.x = o[d][4 * g + 0] * inv; v.y = o[d][4 * g + 1] * inv; v.z = o[d][4 * g + 2] * inv; v.w = o[d][4 * g + 3] * inv;
+          *reinterpret_cast<float4*>(orow + d * 32 + 8 * g) = v;
+        }
+      }
+  }
+}
+
 // ---- split-precision ("bf16x3") form, for the decoder when its FFT blocks run in that arithmetic (the encoder keeps the
 // fp32 kernel above: its output decides durations and buckets).  Same flash-style structure and the same orientation trick,
 // on v_mfma_f32_32x32x16_bf16: every fp32 operand is hi + lo (two bf16) and a product keeps lo*hi + hi*lo + hi*hi.
@@ -343,6 +489,28 @@ __global__ __launch_bounds__(NW * 64) void attention_x3_kernel(const float* __re
 }
 
 }  // namespace
+
+const char* launch_rel_attention(const float* qkv, const float* ps, int ldp, const float* u, float* out, int B, int N, int H, int n_head,
+                                 hipStream_t s) {
+  if (!qkv || !ps || !u || !out) return "rel_attention: null pointer";
+  if (B <= 0 || N <= 0 || n_head <= 0 || H % n_head || ldp < N) return "rel_attention: bad dims";
+  if (B > 65535 || n_head > 65535) return "rel_attention: batch / heads exceed the grid limit";
+  if (((uintptr_t)qkv | (uintptr_t)u | (uintptr_t)out) & 15) return "rel_attention: buffers must be 16-byte aligned";
+  const int dk = H / n_head;
+  const float temperature = sqrtf((float)H);  // sqrt(d_model), not sqrt(d_head) (conformer.py:384)
+  dim3 grid((N + 127) / 128, n_head, B);
+  switch (dk) {
+    case 8: hipLaunchKernelGGL(rel_attention_kernel<8>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
+    case 16: hipLaunchKernelGGL(rel_attention_kernel<16>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
+    case 32: hipLaunchKernelGGL(rel_attention_kernel<32>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
+    case 48: hipLaunchKernelGGL(rel_attention_kernel<48>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
+    case 64: hipLaunchKernelGGL(rel_attention_kernel<64>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
+    case 96: hipLaunchKernelGGL(rel_attention_kernel<96>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
+    default: return "rel_attention: head dim must be one of 8, 16, 32, 48, 64, 96";
+  }
+  hipError_t err = hipGetLastError();
+  return err == hipSuccess ? nullptr : hipGetErrorString(err);
+}
 
 const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head, int x3,
                              hipStream_t s) {

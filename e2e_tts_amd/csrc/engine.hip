@@ -45,6 +45,21 @@ struct FFTLayer {
   const float *wqkv, *bqkv, *wo, *bo, *ln1g, *ln1b, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
   const float *wqkv_x3 = nullptr, *wo_x3 = nullptr, *w1_x3 = nullptr, *w2_x3 = nullptr;  // optional split-precision images
 };
+// Conformer block (U/blocks/conformer.py:171-255), as packed by packer._pack_conformer
+struct CfGemm {
+  const float *w = nullptr, *b = nullptr, *wx3 = nullptr;
+};
+struct CfLayer {
+  const float *ff_lng[2], *ff_lnb[2];
+  CfGemm ff_a[2], ff_b[2];  // FeedForwardModule x 2: Linear(H -> F), Linear(F -> H) (half-step factor folded in)
+  const float *att_lng, *att_lnb, *att_u;
+  CfGemm att_qkv, att_o;
+  const float *pos[2], *posb[2];  // pos_proj(table) per head [n_head][rows][d_head] + v_bias . P bias [n_head][rows4]: stored / regenerated table
+  uint64_t pos_rows[2];
+  const float *cv_lng, *cv_lnb, *dw_w, *dw_b;
+  CfGemm pw1, pw2;
+  const float *lng, *lnb;
+};
 struct PredLayer {
   const float *w, *b, *g, *beta;
 };
@@ -83,6 +98,7 @@ struct e2etts_engine {
   size_t frag_bytes = 0;
   bool ac_loaded = false, voc_loaded = false;
   std::vector<FFTLayer> enc, dec;
+  std::vector<CfLayer> cf_enc, cf_dec;  // cfg.block_type == 1
   Predictor dur, pitch, energy;
   const float *emb = nullptr, *enc_pos = nullptr, *dec_pos = nullptr, *pos_regen = nullptr, *spk_emb = nullptr;
   const float *var_pos = nullptr, *pitch_emb = nullptr, *energy_emb = nullptr, *energy_bins = nullptr;
@@ -98,6 +114,7 @@ struct e2etts_engine {
 
   // workspace
   DevBuf ids, lens64, lens32, spk, xa, xb, xs, xp, tmp, qkv, att, hid, p1, p2;
+  DevBuf relps;  // Conformer: unshifted position scores [B, n_head, N, ceil4(N)]
   DevBuf logd, durf, cum, mel64, mel32, posbuf, ppred, epred, pidx, eidx;
   DevBuf dx, dxb, mel, melpost, pn1, pn2, encout;
   DevBuf melin, v0, v1, v2, v3, wav, pcm;
@@ -340,6 +357,56 @@ int bind_fft(e2etts_engine* e, const char* side, int layers, std::vector<FFTLaye
   return E2ETTS_OK;
 }
 
+int bind_cf_gemm(e2etts_engine* e, const std::string& name, const char* bias, uint64_t cout, uint64_t cin, CfGemm& g) {
+  RET(get_tensor(e, name, cout * cin, &g.w));
+  g.b = nullptr;
+  if (bias) RET(get_tensor(e, bias, cout, &g.b));
+  g.wx3 = nullptr;
+  if (e->tensors.count(name + ".x3")) {
+    RET(get_tensor(e, name + ".x3", cout * ((cin + 31) / 32 * 32), &g.wx3));
+    RET(make_frag(e, g.wx3, cout, 1, cin));
+  }
+  return E2ETTS_OK;
+}
+
+int bind_conformer(e2etts_engine* e, const char* side, int layers, std::vector<CfLayer>& v) {
+  const auto& c = e->cfg;
+  const uint64_t H = c.hidden, F = c.ffn_dim, nh = c.n_head;
+  v.resize(layers);
+  for (int l = 0; l < layers; ++l) {
+    const std::string p = std::string(side) + "." + std::to_string(l) + ".";
+    CfLayer& f = v[l];
+    for (int i = 0; i < 2; ++i) {
+      const std::string q = p + (i ? "ff2." : "ff1.");
+      RET(get_tensor(e, q + "ln.g", H, &f.ff_lng[i]));
+      RET(get_tensor(e, q + "ln.b", H, &f.ff_lnb[i]));
+      RET(bind_cf_gemm(e, q + "w1", (q + "b1").c_str(), F, H, f.ff_a[i]));
+      RET(bind_cf_gemm(e, q + "w2", (q + "b2").c_str(), H, F, f.ff_b[i]));
+    }
+    RET(get_tensor(e, p + "att.ln.g", H, &f.att_lng));
+    RET(get_tensor(e, p + "att.ln.b", H, &f.att_lnb));
+    RET(get_tensor(e, p + "att.u", H, &f.att_u));
+    RET(bind_cf_gemm(e, p + "att.wqkv", nullptr, 3 * H, H, f.att_qkv));  // LinearNorm default: no bias (U/blocks/utils.py:182)
+    RET(bind_cf_gemm(e, p + "att.wo", nullptr, H, H, f.att_o));
+    const uint64_t rows[2] = {(uint64_t)c.max_seq_len + 1, (uint64_t)c.pos_table_rows};
+    const char* tag[2] = {"att.pos", "att.posr"};
+    for (int i = 0; i < 2; ++i) {
+      f.pos_rows[i] = rows[i];
+      RET(get_tensor(e, p + tag[i], nh * rows[i] * (H / nh), &f.pos[i]));
+      RET(get_tensor(e, p + tag[i] + "b", nh * ((rows[i] + 3) / 4 * 4), &f.posb[i]));
+    }
+    RET(get_tensor(e, p + "cv.ln.g", H, &f.cv_lng));
+    RET(get_tensor(e, p + "cv.ln.b", H, &f.cv_lnb));
+    RET(bind_cf_gemm(e, p + "cv.pw1.w", (p + "cv.pw1.b").c_str(), 2 * H, H, f.pw1));
+    RET(get_tensor(e, p + "cv.dw.w", (uint64_t)c.ffn_k1 * H, &f.dw_w));
+    RET(get_tensor(e, p + "cv.dw.b", H, &f.dw_b));
+    RET(bind_cf_gemm(e, p + "cv.pw2.w", (p + "cv.pw2.b").c_str(), H, H, f.pw2));
+    RET(get_tensor(e, p + "ln.g", H, &f.lng));
+    RET(get_tensor(e, p + "ln.b", H, &f.lnb));
+  }
+  return E2ETTS_OK;
+}
+
 int bind_pred(e2etts_engine* e, const char* name, int layers, int kernel, int chans, int odim, bool alpha, Predictor& pr) {
   const uint64_t H = e->cfg.hidden;
   pr.layers.resize(layers);
@@ -368,8 +435,13 @@ int bind_acoustic(e2etts_engine* e) {
   RET(get_tensor(e, "dec.pos", (uint64_t)(c.max_seq_len + 1) * H, &e->dec_pos));
   RET(get_tensor(e, "pos.regen", (uint64_t)c.pos_table_rows * H, &e->pos_regen));
   RET(get_tensor(e, "spk.emb", (uint64_t)c.n_speakers * H, &e->spk_emb));
-  RET(bind_fft(e, "enc", c.enc_layers, e->enc));
-  RET(bind_fft(e, "dec", c.dec_layers, e->dec));
+  if (c.block_type == 1) {
+    RET(bind_conformer(e, "enc", c.enc_layers, e->cf_enc));
+    RET(bind_conformer(e, "dec", c.dec_layers, e->cf_dec));
+  } else {
+    RET(bind_fft(e, "enc", c.enc_layers, e->enc));
+    RET(bind_fft(e, "dec", c.dec_layers, e->dec));
+  }
   RET(bind_pred(e, "dur", c.dur_layers, c.dur_kernel, c.dur_chans, 1, false, e->dur));
   RET(bind_pred(e, "pitch", c.var_layers, c.var_kernel, c.var_chans, 2, true, e->pitch));
   RET(bind_pred(e, "energy", c.var_layers, c.var_kernel, c.var_chans, 1, true, e->energy));
@@ -535,6 +607,87 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
   return E2ETTS_OK;
 }
 
+// n x ConformerBlock (reference U/blocks/conformer.py:214-255), in place on x ([B, N, H]).  Every sub-module is a pre-norm residual
+// unit; nothing inside a block is masked (nn.Sequential hands the attention module no mask, :252, and the depthwise convolution
+// runs over the padded length), so all N rows are computed; only the block's final LayerNorm output is zeroed at rows >= lens[b].
+int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3) {
+  const auto& c = e->cfg;
+  const int H = c.hidden, F = c.ffn_dim, nh = c.n_head, dh = H / nh;
+  const int ldp = (N + 3) / 4 * 4;
+  RET(ensure(e, e->relps, (size_t)B * nh * N * ldp * 4));
+  float* qkv = ptr<float>(e->qkv);
+  float* att = ptr<float>(e->att);
+  float* tmp = ptr<float>(e->tmp);
+  float* hid = ptr<float>(e->hid);
+  float* relps = ptr<float>(e->relps);
+  float *cur = x, *oth = xalt;
+  const int tsel = N > c.max_seq_len ? 1 : 0;  // eval-time regenerated table (:339-344)
+  auto gemm = [&](const CfGemm& g, const float* in, float* out, int cin, int cout, const float* res) -> int {
+    ConvParams p;
+    p.B = B; p.T = N; p.in = in; p.out = out; p.Cin = cin; p.Cout = cout; p.bias = g.b; p.res = res;
+    const bool sx = x3 && g.wx3;
+    p.w = sx ? g.wx3 : g.w; p.x3 = sx;
+    return conv(e, p);
+  };
+  auto ln = [&](const float* in, float* out, const float* g, const float* b, const int32_t* mask) -> int {
+    ProfScope ps(e, "layernorm", 0, 8.0 * B * N * H);
+    KCHK(e, launch_layernorm(in, out, g, b, mask, B, N, H, 1e-5f, e->stream));
+    return E2ETTS_OK;
+  };
+  for (const CfLayer& f : layers) {
+    if ((uint64_t)ldp > f.pos_rows[tsel])
+      return e->fail(E2ETTS_EINVAL, "sequence of %d rows exceeds the Conformer position table (%llu rows)", N, (unsigned long long)f.pos_rows[tsel]);
+    for (int half = 0; half < 2; ++half) {
+      if (half == 1) {
+        // MultiHeadedSelfAttentionModule (:335-353) + RelativeMultiHeadAttention (:399-440)
+        RET(ln(cur, tmp, f.att_lng, f.att_lnb, nullptr));
+        RET(gemm(f.att_qkv, tmp, qkv, H, 3 * H, nullptr));
+        for (int h = 0; h < nh; ++h) {  // position scores (q + v_bias) . P^T of head h for the whole batch: q . P_h^T + (v_h . P_h)
+          ConvParams p;
+          p.B = B; p.T = N; p.in = qkv + h * dh; p.in_ld = 3 * H; p.in_bs = (long long)N * 3 * H; p.Cin = dh;
+          p.w = f.pos[tsel] + (size_t)h * f.pos_rows[tsel] * dh;
+          p.bias = f.posb[tsel] + (size_t)h * ((f.pos_rows[tsel] + 3) / 4 * 4);
+          p.Cout = ldp; p.out = relps + (size_t)h * N * ldp; p.out_ld = ldp; p.out_bs = (long long)nh * N * ldp;
+          RET(conv(e, p));
+        }
+        {
+          const double fl = 4.0 * B * nh * (double)N * N * dh;
+          ProfScope ps(e, "rel_attention", fl, 4.0 * B * ((double)nh * N * ldp + 4.0 * N * H));
+          KCHK(e, launch_rel_attention(qkv, relps, ldp, f.att_u, att, B, N, H, nh, e->stream));
+        }
+        RET(gemm(f.att_o, att, oth, H, H, cur));
+        std::swap(cur, oth);
+        // ConformerConvModule (:468-481): LayerNorm, pointwise 2H + GLU, depthwise k + BatchNorm + Swish, pointwise
+        RET(ln(cur, tmp, f.cv_lng, f.cv_lnb, nullptr));
+        RET(gemm(f.pw1, tmp, hid, H, 2 * H, nullptr));
+        {
+          ProfScope ps(e, "misc", 0, 12.0 * B * N * H);
+          KCHK(e, launch_glu(hid, att, (long long)B * N, H, e->stream));
+        }
+        {
+          ProfScope ps(e, "dwconv_swish", 2.0 * B * N * (double)H * c.ffn_k1, 8.0 * B * N * H);
+          KCHK(e, launch_dwconv_swish(att, f.dw_w, f.dw_b, tmp, B, N, H, c.ffn_k1, e->stream));
+        }
+        RET(gemm(f.pw2, tmp, oth, H, H, cur));
+        std::swap(cur, oth);
+      }
+      // FeedForwardModule (:294-301): LayerNorm, Linear, Swish, Linear; x + factor * ff(x) with the factor folded into the weights
+      RET(ln(cur, tmp, f.ff_lng[half], f.ff_lnb[half], nullptr));
+      RET(gemm(f.ff_a[half], tmp, hid, H, F, nullptr));
+      {
+        ProfScope ps(e, "misc", 0, 8.0 * B * N * F);
+        KCHK(e, launch_swish(hid, (long long)B * N * F, e->stream));
+      }
+      RET(gemm(f.ff_b[half], hid, oth, F, H, cur));
+      std::swap(cur, oth);
+    }
+    RET(ln(cur, oth, f.lng, f.lnb, lens));  // final LayerNorm (:248) + masked_fill (:253-254)
+    std::swap(cur, oth);
+  }
+  if (cur != x) HIPCHK(e, hipMemcpyAsync(x, cur, (size_t)B * N * H * 4, hipMemcpyDeviceToDevice, e->stream));
+  return E2ETTS_OK;
+}
+
 // conv -> ReLU -> channel LayerNorm(eps 1e-12) [-> x (1 - mask)] stack + small Linear
 // (reference DurationPredictor U/layers.py:410-420, VariancePredictor :499-503)
 int predictor(e2etts_engine* e, const Predictor& pr, const float* x, float* out, const int32_t* mask_lens, int B, int L) {
@@ -656,7 +809,8 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_embed(ptr<int64_t>(e->ids), e->emb, pos, x, B, L, H, c.n_symbols + 1, e->stream));
   }
-  RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L, false));  // encoder: always exact fp32
+  if (c.block_type == 1) RET(conformer_stack(e, e->cf_enc, x, ptr<float>(e->xb), tl, B, L, false));
+  else RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L, false));  // encoder: always exact fp32
   HIPCHK(e, hipMemcpyAsync(e->encout.p, x, BL * H * 4, hipMemcpyDeviceToDevice, e->stream));
 
   // Variance adaptor, inference branch (U/layers.py:195-258)
@@ -736,7 +890,9 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     act_dec = ab;
     act_post = ab + B;
   }
-  RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1, act_dec));
+  // (a Conformer decoder computes every row: its attention is unmasked and its depthwise convolution crosses into the padding)
+  if (c.block_type == 1) RET(conformer_stack(e, e->cf_dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1));
+  else RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1, act_dec));
   // mel_linear (U/model.py:186)
   ConvParams p;
   auto setw = [&](ConvParams& q, const ConvW& w) {
@@ -962,6 +1118,12 @@ int e2etts_create(int device_id, const e2etts_config* cfg, e2etts_engine** out) 
   if (c.voc_istft_nfft != 0) {
     const int n = c.voc_istft_nfft;
     if (n < 4 || n > 256 || (n & (n - 1)) || c.voc_istft_hop <= 0 || n % c.voc_istft_hop) return bad("iSTFT: n_fft must be a power of two in [4, 256] and a multiple of the hop");
+  }
+  if (c.block_type != 0 && c.block_type != 1) return bad("block_type must be 0 (FFT block) or 1 (Conformer block)");
+  if (c.block_type == 1) {
+    const int dh = c.hidden / c.n_head;
+    if (dh != 8 && dh != 16 && dh != 32 && dh != 48 && dh != 64 && dh != 96) return bad("Conformer head dim must be one of 8, 16, 32, 48, 64, 96");
+    if (c.ffn_dim < 2 * c.hidden) return bad("Conformer ffn_expansion_factor must be at least 2");
   }
   if (c.n_bins != 256) return bad("n_bins must be 256");
   if (c.pos_table_rows < c.max_seq_len + 1) return bad("pos_table_rows must cover max_seq_len + 1");

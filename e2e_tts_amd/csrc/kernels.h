@@ -107,6 +107,18 @@ const char* launch_reflect_lrelu(const float* in, float* out, int B, long long n
 const char* launch_istft(const float* q, int ldq, float* specphase, float* ri, float* wav, int16_t* pcm, int B, long long F, int nfft,
                          int hop, hipStream_t s);
 
+// Conformer block pieces (reference U/blocks/conformer.py:273-304, 443-481; U/blocks/utils.py:196-219)
+const char* launch_swish(float* x, long long n, hipStream_t s);                                     // x *= sigmoid(x), in place
+const char* launch_glu(const float* in, float* out, long long rows, int C, hipStream_t s);          // [rows, 2C] -> [rows, C]
+// depthwise conv (k taps, zero "same" padding over [0, N), w [k][C], BatchNorm folded into w / bias) + Swish; channels-last
+const char* launch_dwconv_swish(const float* in, const float* w, const float* bias, float* out, int B, int N, int C, int k, hipStream_t s);
+// Relative-position self-attention of RelativeMultiHeadAttention (conformer.py:399-440): no key mask (nn.Sequential passes no mask,
+// :252), score = ((q + u) . k + shift((q + v) . P)) / sqrt(H).  qkv [B, N, 3H] as in launch_attention; u [H] (heads flattened);
+// ps [B, n_head, N, ldp]: the UNSHIFTED position scores (q + v) . P[c], c < N, which _relative_shift (:432-440) re-indexes:
+// (i, j <= i) -> ps[i][N - 1 - i + j]; (i, i + 1) -> 0; (i, j > i + 1) -> ps[i + 1][j - i - 2].  out [B, N, H].
+const char* launch_rel_attention(const float* qkv, const float* ps, int ldp, const float* u, float* out, int B, int N, int H, int n_head,
+                                 hipStream_t s);
+
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s);
 // wav = tanh(conv7(lrelu_0.01(x))) with Cout = 1; pcm = (int16)(int32)(wav * 32768)
 const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,

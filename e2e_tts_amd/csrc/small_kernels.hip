@@ -306,6 +306,55 @@ __global__ void reflect_lrelu_kernel(const float4* __restrict__ in, float4* __re
   out[((long long)b * (n + 1) + f) * c4 + c] = v;
 }
 
+// ---- Conformer block pieces (reference U/blocks/conformer.py, U/blocks/utils.py:196-219) ----
+__device__ __forceinline__ float swish1(float v) { return v * (1.0f / (1.0f + expf(-v))); }
+
+// x = x * sigmoid(x) in place (Swish between the two Linear layers of FeedForwardModule, conformer.py:294-301)
+__global__ void swish_kernel(float4* __restrict__ x, long long n4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = x[i];
+  v.x = swish1(v.x); v.y = swish1(v.y); v.z = swish1(v.z); v.w = swish1(v.w);
+  x[i] = v;
+}
+
+// GLU over channels (conformer.py:472, utils.py:217-219): out[row, c] = in[row, c] * sigmoid(in[row, C + c])
+__global__ void glu_kernel(const float4* __restrict__ in, float4* __restrict__ out, long long rows, int c4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c4) return;
+  const long long row = i / c4;
+  const int c = (int)(i - row * c4);
+  const float4 a = in[row * 2 * c4 + c], g = in[row * 2 * c4 + c4 + c];
+  float4 v;
+  v.x = a.x * (1.0f / (1.0f + expf(-g.x))); v.y = a.y * (1.0f / (1.0f + expf(-g.y)));
+  v.z = a.z * (1.0f / (1.0f + expf(-g.z))); v.w = a.w * (1.0f / (1.0f + expf(-g.w)));
+  out[i] = v;
+}
+
+// Depthwise Conv1d(k, "same", no bias) -> BatchNorm1d (eval; folded into w / b by the packer) -> Swish (conformer.py:473-475) on
+// channels-last rows.  The convolution runs over the whole padded length N: nothing masks padded frames inside a Conformer block.
+// w: [k][C] tap-major.  One thread = 4 channels of one frame; the k re-reads of a frame come from L1 / L2.
+__global__ void dwconv_swish_kernel(const float4* __restrict__ in, const float4* __restrict__ w, const float4* __restrict__ bias,
+                                    float4* __restrict__ out, int N, int c4, int k) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (n, c) inside one utterance
+  const int b = blockIdx.y;
+  if (i >= (long long)N * c4) return;
+  const int n = (int)(i / c4), c = (int)(i - (long long)n * c4);
+  const float4* xb = in + (long long)b * N * c4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int half = (k - 1) / 2;
+  for (int j = 0; j < k; ++j) {
+    const int t = n - half + j;
+    if (t < 0 || t >= N) continue;
+    const float4 x = xb[(long long)t * c4 + c], ww = w[j * c4 + c];
+    acc.x = fmaf(x.x, ww.x, acc.x); acc.y = fmaf(x.y, ww.y, acc.y); acc.z = fmaf(x.z, ww.z, acc.z); acc.w = fmaf(x.w, ww.w, acc.w);
+  }
+  const float4 bb = bias[c];
+  float4 v;
+  v.x = swish1(acc.x + bb.x); v.y = swish1(acc.y + bb.y); v.z = swish1(acc.z + bb.z); v.w = swish1(acc.w + bb.w);
+  out[(long long)b * N * c4 + i] = v;
+}
+
 // spec = exp(q[:bins]), phase = sin(q[bins:2 bins]) (V/generator.py:110-111); X = spec * exp(j phase) (stft.py:141)
 __global__ void istft_prep_kernel(const float* __restrict__ q, int ldq, float* __restrict__ specphase, float2* __restrict__ ri,
                                   long long total, int bins) {
@@ -527,6 +576,30 @@ const char* launch_reflect_lrelu(const float* in, float* out, int B, long long n
   hipLaunchKernelGGL(reflect_lrelu_kernel, dim3((unsigned)((items + 255) / 256), B), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), n, C / 4, slope);
   return CHECK_LAUNCH("reflect_lrelu");
+}
+
+const char* launch_swish(float* x, long long n, hipStream_t s) {
+  if (!x || n <= 0 || n % 4 || ((uintptr_t)x & 15)) return "swish: bad buffer";
+  hipLaunchKernelGGL(swish_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<float4*>(x), n / 4);
+  return CHECK_LAUNCH("swish");
+}
+
+const char* launch_glu(const float* in, float* out, long long rows, int C, hipStream_t s) {
+  if (!in || !out || rows <= 0 || C <= 0 || C % 4 || (((uintptr_t)in | (uintptr_t)out) & 15)) return "glu: bad arguments";
+  const long long items = rows * (C / 4);
+  hipLaunchKernelGGL(glu_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(in),
+                     reinterpret_cast<float4*>(out), rows, C / 4);
+  return CHECK_LAUNCH("glu");
+}
+
+const char* launch_dwconv_swish(const float* in, const float* w, const float* bias, float* out, int B, int N, int C, int k, hipStream_t s) {
+  if (!in || !w || !bias || !out || in == out) return "dwconv: null or aliased pointer";
+  if (B <= 0 || N <= 0 || C <= 0 || C % 4 || k <= 0 || k % 2 == 0) return "dwconv: channels must be a multiple of 4, kernel odd";
+  if (((uintptr_t)in | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out) & 15) return "dwconv: buffers must be 16-byte aligned";
+  const long long items = (long long)N * (C / 4);
+  hipLaunchKernelGGL(dwconv_swish_kernel, dim3((unsigned)((items + 255) / 256), B), dim3(256), 0, s, reinterpret_cast<const float4*>(in),
+                     reinterpret_cast<const float4*>(w), reinterpret_cast<const float4*>(bias), reinterpret_cast<float4*>(out), N, C / 4, k);
+  return CHECK_LAUNCH("dwconv_swish");
 }
 
 const char* launch_istft(const float* q, int ldq, float* specphase, float* ri, float* wav, int16_t* pcm, int B, long long F, int nfft,

@@ -136,6 +136,68 @@ def _need(sd, key, shape=None):
     return t.astype(np.float32) if t.dtype.kind == "f" else t
 
 
+def _pack_conformer(dims: EngineDims, A, out) -> None:
+    """Conformer blocks (reference U/blocks/conformer.py:171-255) -> engine tensors `enc.N.*` / `dec.N.*` (bind_conformer()).
+
+    Folded here: the half-step factor into the second FFN Linear (x 0.5 is exact); BatchNorm (eval) into the depthwise conv;
+    pos_proj(position table) per layer -- it does not depend on the input -- laid out per head [n_head][rows][d_head], once from
+    the stored table (`att.pos`, N <= max_seq_len) and once from the regenerated one (`att.posr`, conformer.py:339-344); and
+    v_bias . P[c] as the bias vector of the position-score GEMM (`att.posb`, rows padded to a multiple of 4 per head)."""
+    H, F, nh, k = dims.hidden, dims.ffn_dim, dims.n_head, dims.ffn_k1
+    dh = H // nh
+    need = _need
+    regen = sinusoid_table(dims.pos_table_rows, H)
+    for side, short, n in (("encoder", "enc", dims.enc_layers), ("decoder", "dec", dims.dec_layers)):
+        for l in range(n):
+            s = f"{side}.layer_stack.{l}.sequential"
+            q = f"{short}.{l}."
+            gemms = []
+            for i, nm in ((0, "ff1"), (3, "ff2")):
+                m = f"{s}.{i}.module.sequential"
+                out[q + nm + ".ln.g"] = need(A, f"{m}.0.weight", (H,))
+                out[q + nm + ".ln.b"] = need(A, f"{m}.0.bias", (H,))
+                out[q + nm + ".w1"] = need(A, f"{m}.1.linear.weight", (F, H))
+                out[q + nm + ".b1"] = need(A, f"{m}.1.linear.bias", (F,))
+                out[q + nm + ".w2"] = need(A, f"{m}.4.linear.weight", (H, F)) * np.float32(dims.cf_ffn_factor)
+                out[q + nm + ".b2"] = need(A, f"{m}.4.linear.bias", (H,)) * np.float32(dims.cf_ffn_factor)
+                gemms += [(nm + ".w1", H), (nm + ".w2", F)]
+            a = f"{s}.1.module"
+            out[q + "att.ln.g"] = need(A, f"{a}.layer_norm.weight", (H,))
+            out[q + "att.ln.b"] = need(A, f"{a}.layer_norm.bias", (H,))
+            out[q + "att.wqkv"] = np.concatenate(
+                [need(A, f"{a}.attention.{w}.linear.weight", (H, H)) for w in ("query_proj", "key_proj", "value_proj")], 0)
+            out[q + "att.wo"] = need(A, f"{a}.attention.out_proj.linear.weight", (H, H))
+            out[q + "att.u"] = need(A, f"{a}.attention.u_bias", (nh, dh)).reshape(H)
+            wp = need(A, f"{a}.attention.pos_proj.linear.weight", (H, H))
+            vb = need(A, f"{a}.attention.v_bias", (nh, dh))
+            stored = need(A, f"{a}.positional_encoding", (1, dims.max_seq_len + 1, H))[0]
+            for tag, table in (("pos", stored), ("posr", regen)):
+                rows = table.shape[0]
+                ph = np.ascontiguousarray((table @ wp.T).astype(np.float32).reshape(rows, nh, dh).transpose(1, 0, 2))
+                pb = np.zeros((nh, (rows + 3) // 4 * 4), np.float32)
+                pb[:, :rows] = np.einsum("hrd,hd->hr", ph, vb)
+                out[q + f"att.{tag}"] = ph
+                out[q + f"att.{tag}b"] = pb
+            m = f"{s}.2.module.sequential"
+            out[q + "cv.ln.g"] = need(A, f"{m}.0.weight", (H,))
+            out[q + "cv.ln.b"] = need(A, f"{m}.0.bias", (H,))
+            out[q + "cv.pw1.w"] = need(A, f"{m}.2.conv.weight", (2 * H, H, 1))[:, :, 0]
+            out[q + "cv.pw1.b"] = need(A, f"{m}.2.conv.bias", (2 * H,))
+            dw = need(A, f"{m}.4.conv.weight", (H, 1, k))[:, 0, :].astype(np.float64)
+            scale = need(A, f"{m}.5.weight", (H,)).astype(np.float64) / np.sqrt(need(A, f"{m}.5.running_var", (H,)).astype(np.float64) + 1e-5)
+            out[q + "cv.dw.w"] = np.ascontiguousarray((dw * scale[:, None]).T).astype(np.float32)            # [k][H]
+            out[q + "cv.dw.b"] = (need(A, f"{m}.5.bias", (H,)).astype(np.float64)
+                                  - need(A, f"{m}.5.running_mean", (H,)).astype(np.float64) * scale).astype(np.float32)
+            out[q + "cv.pw2.w"] = need(A, f"{m}.7.conv.weight", (H, H, 1))[:, :, 0]
+            out[q + "cv.pw2.b"] = need(A, f"{m}.7.conv.bias", (H,))
+            out[q + "ln.g"] = need(A, f"{s}.4.weight", (H,))
+            out[q + "ln.b"] = need(A, f"{s}.4.bias", (H,))
+            gemms += [("att.wqkv", H), ("att.wo", H), ("cv.pw1.w", H), ("cv.pw2.w", H)]
+            if short == "dec":  # as for the FFT blocks: only the decoder may run split-precision
+                for nm, cin in gemms:
+                    out[q + nm + ".x3"] = pack_x3(np.ascontiguousarray(out[q + nm]), 1, cin)
+
+
 def _pack_acoustic(dims: EngineDims, A, out) -> None:
     H = dims.hidden
     need = _need
@@ -144,8 +206,10 @@ def _pack_acoustic(dims: EngineDims, A, out) -> None:
     out["dec.pos"] = need(A, "decoder.position_enc", (1, dims.max_seq_len + 1, H))[0]
     out["pos.regen"] = sinusoid_table(dims.pos_table_rows, H)
     out["spk.emb"] = need(A, "speaker_emb.weight", (dims.n_speakers, H))
+    if dims.block_type == 1:
+        _pack_conformer(dims, A, out)
     for side, short, n in (("encoder", "enc", dims.enc_layers), ("decoder", "dec", dims.dec_layers)):
-        for l in range(n):
+        for l in range(n if dims.block_type == 0 else 0):
             p = f"{side}.layer_stack.{l}"
             q = f"{short}.{l}."
             out[q + "wqkv"] = np.concatenate([need(A, f"{p}.slf_attn.{w}.weight", (H, H)) for w in ("w_qs", "w_ks", "w_vs")], 0)

@@ -39,10 +39,14 @@ def sinusoid_table(n_position: int, d_hid: int) -> np.ndarray:
 def acoustic_manifest(config: dict, n_speakers: int, n_symbols: int = N_SYMBOLS) -> "OrderedDict[str, Tuple[Shape, str]]":
     """name -> (shape, kind) for UnsupervisedFastSpeech2.state_dict()."""
     fs = config["models"]["fastspeech2"]
-    tr = fs["building_block"]["transformer"]
+    bt = fs["building_block"]["block_type"]
+    tr = fs["building_block"][bt]
     H = fs["encoder_hidden"]
-    F = tr["conv_filter_size"]
-    k1, k2 = tr["conv_kernel_size"]
+    if bt == "conformer":
+        F, k1, k2 = H * tr["ffn_expansion_factor"], tr["conv_kernel_size"], 1
+    else:
+        F = tr["conv_filter_size"]
+        k1, k2 = tr["conv_kernel_size"]
     n_mel = config["audio"]["mel"]["channels"]
     vp = fs["variance"]["variance_predictor"]
     ve = fs["variance"]["variance_embedding"]
@@ -56,7 +60,42 @@ def acoustic_manifest(config: dict, n_speakers: int, n_symbols: int = N_SYMBOLS)
         add(f"{side}.position_enc", (1, fs["max_seq_len"] + 1, H), "posenc")
         if side == "encoder":
             add("encoder.src_word_emb.weight", (n_symbols + 1, H), "emb_pad0")
-        for l in range(layers):
+        for l in range(layers if bt == "conformer" else 0):
+            # ConformerBlock.state_dict() (U/blocks/conformer.py:214-249): FFN, rel-pos MHSA, conv module, FFN, LayerNorm
+            p = f"{side}.layer_stack.{l}.sequential"
+            nh = tr[f"{side}_head"]
+            for i in (0, 3):
+                q = f"{p}.{i}.module.sequential"
+                add(f"{q}.0.weight", (H,), "gamma")
+                add(f"{q}.0.bias", (H,), "beta")
+                add(f"{q}.1.linear.weight", (F, H), "w")
+                add(f"{q}.1.linear.bias", (F,), "b")
+                add(f"{q}.4.linear.weight", (H, F), "w")
+                add(f"{q}.4.linear.bias", (H,), "b")
+            q = f"{p}.1.module"
+            add(f"{q}.positional_encoding", (1, fs["max_seq_len"] + 1, H), "posenc")  # the side's table, registered again (:330)
+            add(f"{q}.layer_norm.weight", (H,), "gamma")
+            add(f"{q}.layer_norm.bias", (H,), "beta")
+            add(f"{q}.attention.u_bias", (nh, H // nh), "emb")
+            add(f"{q}.attention.v_bias", (nh, H // nh), "emb")
+            for w in ("query_proj", "key_proj", "value_proj", "pos_proj", "out_proj"):
+                add(f"{q}.attention.{w}.linear.weight", (H, H), "w")  # LinearNorm default: no bias (U/blocks/utils.py:182)
+            q = f"{p}.2.module.sequential"
+            add(f"{q}.0.weight", (H,), "gamma")
+            add(f"{q}.0.bias", (H,), "beta")
+            add(f"{q}.2.conv.weight", (2 * H, H, 1), "w")
+            add(f"{q}.2.conv.bias", (2 * H,), "b")
+            add(f"{q}.4.conv.weight", (H, 1, k1), "w")
+            add(f"{q}.5.weight", (H,), "gamma")
+            add(f"{q}.5.bias", (H,), "beta")
+            add(f"{q}.5.running_mean", (H,), "bn_mean")
+            add(f"{q}.5.running_var", (H,), "bn_var")
+            add(f"{q}.5.num_batches_tracked", (), "i64")
+            add(f"{q}.7.conv.weight", (H, H, 1), "w")
+            add(f"{q}.7.conv.bias", (H,), "b")
+            add(f"{p}.4.weight", (H,), "gamma")
+            add(f"{p}.4.bias", (H,), "beta")
+        for l in range(0 if bt == "conformer" else layers):
             p = f"{side}.layer_stack.{l}"
             for w in ("w_qs", "w_ks", "w_vs", "fc"):
                 add(f"{p}.slf_attn.{w}.weight", (H, H), "w")

@@ -69,6 +69,9 @@ typedef struct e2etts_config {
   int32_t voc_istft_nfft; /* 0: HiFi-GAN tail (conv_post -> tanh, V/generator.py:49-51); else the iSTFTNet tail (V/generator.py:107-113 +
                              src/tools/stft.py:138-148): conv_post to n_fft + 2 channels, exp / sin, inverse STFT */
   int32_t voc_istft_hop;  /* iSTFT hop; prod(voc_up_rate) * voc_istft_hop == hop_length */
+  int32_t block_type;     /* encoder / decoder block: 0 = FFT block (U/blocks/transformer.py:178-189); 1 = Conformer block
+                             (U/blocks/conformer.py:171-255): n_head relative-position heads, ffn_dim = hidden x ffn_expansion_factor,
+                             ffn_k1 = depthwise kernel size */
 } e2etts_config;
 
 typedef struct e2etts_engine e2etts_engine;

@@ -447,6 +447,9 @@ def main():
     args = ap.parse_args()
     models = import_reference()
     tiny, full = cfgmod.tiny_config(), cfgmod.default_config()
+    tiny_cf, full_cf = cfgmod.tiny_config(), cfgmod.default_config()   # block_type "conformer" (U/model.py:26-27)
+    for c in (tiny_cf, full_cf):
+        c["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"
     jobs = {
         "tables": lambda: case_tables(models),
         "host_loop": case_host_loop,
@@ -457,6 +460,10 @@ def main():
         "tiny_long": lambda: case_model(models, "tiny_long", tiny, "varied", [70, 33], 2, (1.0, 1.0, 1.0), 200, 2e-3, "full"),
         "tiny_ctl": lambda: case_model(models, "tiny_ctl", tiny, "varied", [12, 30, 30, 5], 0, (1.3, 0.9, 1.1), 300, 2e-3, "full"),
         "tiny_b1": lambda: case_model(models, "tiny_b1", tiny, "varied", [1], 3, (1.0, 1.0, 1.0), 400, 2e-3, "full"),
+        # Conformer blocks: tiny_cf_long runs past max_seq_len = 60 (regenerated tables in encoder, decoder and every MHSA module)
+        "tiny_cf_b3": lambda: case_model(models, "tiny_cf_b3", tiny_cf, "varied", [23, 17, 9], 1, (1.0, 1.0, 1.0), 600, 2e-3, "full"),
+        "tiny_cf_long": lambda: case_model(models, "tiny_cf_long", tiny_cf, "varied", [70, 33], 2, (1.1, 0.9, 1.2), 700, 2e-3, "full"),
+        "full_cf_b2": lambda: case_model(models, "full_cf_b2", full_cf, "varied", [40, 27], 1, (1.0, 1.0, 1.0), 800, 1e-3, "medium"),
         "c1_plumbing": lambda: case_model(models, "c1_plumbing", full, "varied", [40], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
         "full_b3": lambda: case_model(models, "full_b3", full, "varied", [48, 31, 20], 1, (1.0, 1.0, 1.0), 500, 1e-3, "medium"),
     }

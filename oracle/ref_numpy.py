@@ -193,7 +193,8 @@ class AcousticOracle:
         self.dt = np.dtype(dtype).type
         self.sd = {k: (v.astype(dtype) if v.dtype.kind == "f" else v) for k, v in state.items()}
         self.fs = config["models"]["fastspeech2"]
-        self.tr = self.fs["building_block"]["transformer"]
+        self.bt = self.fs["building_block"]["block_type"]  # "transformer" | "conformer" (U/model.py:24-27)
+        self.tr = self.fs["building_block"][self.bt]
         self.stats = stats
         self.H = self.fs["encoder_hidden"]
         self.n_head = self.tr["encoder_head"]
@@ -236,6 +237,69 @@ class AcousticOracle:
         x = self.pos_ffn(p + ".pos_ffn", x)
         return np.where(pad[:, :, None], self.dt(0), x)
 
+    # ---- Conformer block (U/blocks/conformer.py:171-255); every sub-module is wrapped in ResidualConnectionModule (:258-270)
+    # U/blocks/conformer.py:273-304: LayerNorm -> Linear -> Swish -> Linear (bias on both: LinearNorm(bias=True))
+    def cf_ffn(self, p: str, x: np.ndarray) -> np.ndarray:
+        sd = self.sd
+        h = layer_norm(x, sd[p + ".0.weight"], sd[p + ".0.bias"], 1e-5)
+        h = linear(h, sd[p + ".1.linear.weight"], sd[p + ".1.linear.bias"])
+        h = h * (self.dt(1) / (self.dt(1) + np.exp(-h)))                 # Swish, U/blocks/utils.py:204-205
+        return linear(h, sd[p + ".4.linear.weight"], sd[p + ".4.linear.bias"])
+
+    # U/blocks/conformer.py:335-353 + 399-440.  nn.Sequential calls the module with ONE argument (:252), so mask is None: no key is
+    # masked, padded rows take part.  Projections have no bias (LinearNorm default); the score is divided by sqrt(d_model) (:384, :418).
+    def cf_mhsa(self, p: str, x: np.ndarray) -> np.ndarray:
+        sd, nh = self.sd, self.n_head
+        B, N, H = x.shape
+        dh = H // nh
+        pos = (sinusoid_table(N, H).astype(self.dt) if N > self.max_seq_len else sd[p + ".positional_encoding"][0, :N])  # :339-348
+        y = layer_norm(x, sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"], 1e-5)
+        a = p + ".attention."
+        q = linear(y, sd[a + "query_proj.linear.weight"], None).reshape(B, N, nh, dh)
+        k = linear(y, sd[a + "key_proj.linear.weight"], None).reshape(B, N, nh, dh).transpose(0, 2, 1, 3)
+        v = linear(y, sd[a + "value_proj.linear.weight"], None).reshape(B, N, nh, dh).transpose(0, 2, 1, 3)
+        pe = linear(pos, sd[a + "pos_proj.linear.weight"], None).reshape(N, nh, dh)
+        content = np.matmul((q + sd[a + "u_bias"]).transpose(0, 2, 1, 3), k.transpose(0, 1, 3, 2))        # [B, nh, N, N]
+        pscore = np.matmul((q + sd[a + "v_bias"]).transpose(0, 2, 1, 3), pe.transpose(1, 2, 0)[None])    # [B, nh, N, N]
+        # _relative_shift (:432-440): prepend a zero column, view as [N + 1, N], drop the first row, view as [N, N]
+        padded = np.concatenate([np.zeros((B, nh, N, 1), self.dt), pscore], axis=-1).reshape(B, nh, N + 1, N)
+        pscore = padded[:, :, 1:].reshape(B, nh, N, N)
+        score = (content + pscore) / self.dt(math.sqrt(H))
+        ctx = np.matmul(softmax_lastdim(score), v).transpose(0, 2, 1, 3).reshape(B, N, H)
+        return linear(ctx, sd[a + "out_proj.linear.weight"], None)
+
+    # U/blocks/conformer.py:468-481: LayerNorm -> pointwise 2H -> GLU -> depthwise k (no bias) -> BatchNorm (eval) -> Swish -> pointwise
+    def cf_conv(self, p: str, x: np.ndarray) -> np.ndarray:
+        sd = self.sd
+        h = layer_norm(x, sd[p + ".0.weight"], sd[p + ".0.bias"], 1e-5).transpose(0, 2, 1)
+        h = conv1d(h, sd[p + ".2.conv.weight"], sd[p + ".2.conv.bias"])
+        C = h.shape[1] // 2
+        h = h[:, :C] * (self.dt(1) / (self.dt(1) + np.exp(-h[:, C:])))  # GLU(dim=1), U/blocks/utils.py:217-219
+        w = sd[p + ".4.conv.weight"]                                    # [C, 1, k], groups = C
+        k = w.shape[2]
+        hp = np.pad(h, ((0, 0), (0, 0), ((k - 1) // 2, (k - 1) // 2)))
+        acc = np.zeros_like(h)
+        for j in range(k):
+            acc += hp[:, :, j:j + h.shape[2]] * w[None, :, 0, j, None]
+        inv = self.dt(1) / np.sqrt(sd[p + ".5.running_var"] + self.dt(1e-5))
+        h = (acc - sd[p + ".5.running_mean"][None, :, None]) * inv[None, :, None] * sd[p + ".5.weight"][None, :, None] \
+            + sd[p + ".5.bias"][None, :, None]
+        h = h * (self.dt(1) / (self.dt(1) + np.exp(-h)))
+        return conv1d(h, sd[p + ".7.conv.weight"], sd[p + ".7.conv.bias"]).transpose(0, 2, 1)
+
+    def conformer_block(self, p: str, x: np.ndarray, pad: np.ndarray) -> np.ndarray:
+        sd, s = self.sd, p + ".sequential"
+        f = self.dt(0.5 if self.tr["half_step_residual"] else 1.0)      # :209-212
+        x = self.cf_ffn(s + ".0.module.sequential", x) * f + x
+        x = self.cf_mhsa(s + ".1.module", x) + x
+        x = self.cf_conv(s + ".2.module.sequential", x) + x
+        x = self.cf_ffn(s + ".3.module.sequential", x) * f + x
+        x = layer_norm(x, sd[s + ".4.weight"], sd[s + ".4.bias"], 1e-5)
+        return np.where(pad[:, :, None], self.dt(0), x)                 # :253-254
+
+    def block(self, p: str, x: np.ndarray, pad: np.ndarray) -> np.ndarray:
+        return self.conformer_block(p, x, pad) if self.bt == "conformer" else self.fft_block(p, x, pad)
+
     def _pos_enc(self, side: str, n: int) -> np.ndarray:
         # eval-time regeneration when the sequence exceeds max_seq_len
         # (U/blocks/transformer.py:68-77 encoder, :138-153 decoder)
@@ -247,14 +311,14 @@ class AcousticOracle:
     def encoder(self, ids: np.ndarray, pad: np.ndarray) -> np.ndarray:
         x = self.sd["encoder.src_word_emb.weight"][ids] + self._pos_enc("encoder", ids.shape[1])[None]
         for l in range(self.fs["encoder_layers"]):
-            x = self.fft_block(f"encoder.layer_stack.{l}", x, pad)
+            x = self.block(f"encoder.layer_stack.{l}", x, pad)
         return x
 
     # U/blocks/transformer.py:132-164
     def decoder(self, x: np.ndarray, pad: np.ndarray) -> np.ndarray:
         x = x + self._pos_enc("decoder", x.shape[1])[None]
         for l in range(self.fs["decoder_layers"]):
-            x = self.fft_block(f"decoder.layer_stack.{l}", x, pad)
+            x = self.block(f"decoder.layer_stack.{l}", x, pad)
         return x
 
     # U/layers.py:410-420 (ctor :382-408); channel LayerNorm eps 1e-12: U/sublayers.py:151-170

@@ -30,7 +30,10 @@ def golden():
 
 def config_for(name):
     from e2e_tts_amd import config as cfgmod
-    return cfgmod.tiny_config() if name.startswith("tiny") or name.startswith("voc_micro") else cfgmod.default_config()
+    cfg = cfgmod.tiny_config() if name.startswith("tiny") or name.startswith("voc_micro") else cfgmod.default_config()
+    if "_cf_" in name:  # fixtures made with building_block.block_type = "conformer" (oracle/make_goldens.py)
+        cfg["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"
+    return cfg
 
 
 _STATE_CACHE = {}
@@ -40,7 +43,7 @@ def states_for(g, name):
     """Regenerate the synthetic state dicts a fixture was made with (seeds + mode are stored in it)."""
     from e2e_tts_amd import config as cfgmod, synth_weights as sw
     cfg = config_for(name)
-    key = (name.startswith("tiny"), str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
+    key = (name.startswith("tiny"), "_cf_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
     if key not in _STATE_CACHE:
         ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=int(g["weight_seeds"][0]), mode=str(g["mode"]))
         voc = sw.make_vocoder_state(cfg, seed=int(g["weight_seeds"][1]))

@@ -22,7 +22,7 @@ _ENGINES = {}
 def engine_for(g, name):
     from e2e_tts_amd.runtime import engine_from_states
     cfg, ac, voc = states_for(g, name)
-    key = (name.startswith("tiny"), str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
+    key = (name.startswith("tiny"), "_cf_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
     if key not in _ENGINES:
         _ENGINES[key] = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)
     return cfg, _ENGINES[key]
@@ -49,7 +49,9 @@ def check_discrete(r, g):
     np.testing.assert_array_equal(r["energy_idx"], g["energy_idx"])
 
 
-@pytest.mark.parametrize("name", ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1"])
+# *_cf_*: the same model with Conformer blocks (building_block.block_type = "conformer", reference U/blocks/conformer.py);
+# tiny_cf_long runs past max_seq_len in the encoder and the decoder (regenerated position tables in every attention module)
+@pytest.mark.parametrize("name", ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1", "tiny_cf_b3", "tiny_cf_long"])
 def test_tiny_model_full_trace(name):
     g = load_golden(name)
     cfg, eng = engine_for(g, name)
@@ -83,7 +85,7 @@ def test_tiny_model_full_trace(name):
         assert close.mean() >= 0.999, prec
 
 
-@pytest.mark.parametrize("name", ["c1_plumbing", "full_b3", "c2_latency"])
+@pytest.mark.parametrize("name", ["c1_plumbing", "full_b3", "c2_latency", "full_cf_b2"])
 def test_default_model(name):
     g = load_golden(name)
     cfg, eng = engine_for(g, name)
@@ -197,7 +199,7 @@ def test_error_paths():
         eng.load_weights(np.zeros(64, np.uint8))                                  # not a blob
 
 
-@pytest.mark.parametrize("name", ["tiny_b3", "tiny_ctl", "full_b3", "c3_mixed"])
+@pytest.mark.parametrize("name", ["tiny_b3", "tiny_ctl", "full_b3", "c3_mixed", "tiny_cf_b3"])
 def test_ragged_synthesize_is_bit_identical_on_valid_samples(name):
     """synthesize() with ragged compute (skip what no valid sample depends on) vs the full padded batch: same PCM on every
     valid sample, and within 1 LSB of the reference's waveform there."""

@@ -115,9 +115,13 @@ def test_blob_roundtrip_and_batchnorm_fold():
 
 def test_config_rejects_unimplemented_variants():
     cfg = cfgmod.default_config()
-    cfg["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"
+    cfg["models"]["fastspeech2"]["building_block"]["block_type"] = "lstransformer"
     with pytest.raises(NotImplementedError):
         cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4)
+    cfg["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"   # implemented: 8 relative-position heads, FFN x4, k31
+    d = cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4)
+    assert (d.block_type, d.n_head, d.ffn_dim, d.ffn_k1, d.ffn_k2, d.cf_ffn_factor) == (1, 8, 1536, 31, 1, 0.5)
+    assert cfgmod.dims_from_config(cfgmod.default_config(), cfgmod.DEFAULT_STATS, 4).block_type == 0
     cfg = cfgmod.default_config()
     cfg["models"]["hifigan"]["resblock"] = 2   # ResBlock2: implemented (two dilations per kernel size)
     assert cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4).voc_rb_dil == [[1, 3]] * 3
@@ -145,7 +149,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert ctypes.sizeof(cfgmod.CEngineConfig) == 4 * (23 + 8 + 8 + 1 + 4 + 1 + 16 + 3) + 8 + 4 * 3  # + voc_resblock, voc_istft_nfft, voc_istft_hop
+    assert ctypes.sizeof(cfgmod.CEngineConfig) == 4 * (23 + 8 + 8 + 1 + 4 + 1 + 16 + 3) + 8 + 4 * 4  # + voc_resblock, voc_istft_nfft, voc_istft_hop, block_type
 
 
 def test_engine_fails_loudly_without_gpu():

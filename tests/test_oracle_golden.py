@@ -11,7 +11,8 @@ from conftest import load_golden, states_for
 from e2e_tts_amd import config as cfgmod
 from oracle import ref_numpy as orc
 
-MODEL_CASES = ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1", "c1_plumbing", "full_b3"]
+MODEL_CASES = ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1", "c1_plumbing", "full_b3",
+               "tiny_cf_b3", "tiny_cf_long", "full_cf_b2"]  # *_cf_*: Conformer blocks (U/blocks/conformer.py)
 
 
 def mean_l1(a, b):

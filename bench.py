@@ -81,6 +81,9 @@ def main():
                          "padded to 200 -> T=1200), value = VALID samples/s")
     ap.add_argument("--precision", choices=("fp32", "bf16x3"), default="bf16x3",
                     help="vocoder arithmetic: exact fp32 MFMA, or split-precision bf16x3 MFMA (default; wav error ~1e-6)")
+    ap.add_argument("--blocks", choices=("transformer", "conformer"), default="transformer",
+                    help="encoder / decoder building block (reference model_config.yaml:8): the headline number is quoted on the default "
+                         "'transformer' FFT blocks; 'conformer' times the same workload with Conformer blocks")
     args = ap.parse_args()
 
     import torch
@@ -110,6 +113,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cfg = cfgmod.default_config()
+    cfg["models"]["fastspeech2"]["building_block"]["block_type"] = args.blocks
     stats = cfgmod.DEFAULT_STATS
     dims = cfgmod.dims_from_config(cfg, stats, n_speakers=4)
     hop = dims.hop_length
@@ -275,7 +279,8 @@ def main():
             "config": {"workload": (f"B={B}/GPU fixed-length L={L} phonemes x {FRAMES_PER_PHONEME} frames = T={T} frames "
                                     f"({T * hop} samples, {T * hop / dims.sample_rate:.2f} s) per utterance" if args.workload == "fixed" else
                                     f"B={B}/GPU mixed lengths 40..200 phonemes padded to L={L} (T={T}), {valid_frames} valid frames")
-                                   + "; default model_config (6+6 FFT blocks H=384, HiFi-GAN V1), random-init weights",
+                                   + ("; default model_config (6+6 FFT blocks H=384, HiFi-GAN V1), random-init weights" if args.blocks == "transformer"
+                                      else "; model_config with block_type=conformer (6+6 Conformer blocks H=384, 8 heads, k31; HiFi-GAN V1), random-init weights"),
                        "sample_rate": dims.sample_rate, "global_batch": world * B, "parallelism": f"utterance-sharded x{world}"},
             "real_time_factor": value / dims.sample_rate,
             "host_inclusive_samples_per_s_per_gpu": host_rate,

@@ -78,6 +78,7 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   if (act == ACT_TANH) return tanhf(v);
   if (act == ACT_LRELU) return v >= 0.f ? v : v * slope;
+  if (act == ACT_SWISH) return v * (1.0f / (1.0f + expf(-v)));
   return v;
 }
 
@@ -328,6 +329,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
           v.x = fmaxf(v.x, v.x * eslope); v.y = fmaxf(v.y, v.y * eslope);
           v.z = fmaxf(v.z, v.z * eslope); v.w = fmaxf(v.w, v.w * eslope);
           if (p.act == ACT_TANH) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+          if (p.act == ACT_SWISH) {
+            v.x *= 1.0f / (1.0f + expf(-v.x)); v.y *= 1.0f / (1.0f + expf(-v.y));
+            v.z *= 1.0f / (1.0f + expf(-v.z)); v.w *= 1.0f / (1.0f + expf(-v.w));
+          }
           if constexpr (RES) {
             const float4 rv = resv[hh][ps];
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;

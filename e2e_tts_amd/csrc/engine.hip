@@ -622,9 +622,9 @@ int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, float*
   float* relps = ptr<float>(e->relps);
   float *cur = x, *oth = xalt;
   const int tsel = N > c.max_seq_len ? 1 : 0;  // eval-time regenerated table (:339-344)
-  auto gemm = [&](const CfGemm& g, const float* in, float* out, int cin, int cout, const float* res) -> int {
+  auto gemm = [&](const CfGemm& g, const float* in, float* out, int cin, int cout, const float* res, int act = ACT_NONE) -> int {
     ConvParams p;
-    p.B = B; p.T = N; p.in = in; p.out = out; p.Cin = cin; p.Cout = cout; p.bias = g.b; p.res = res;
+    p.B = B; p.T = N; p.in = in; p.out = out; p.Cin = cin; p.Cout = cout; p.bias = g.b; p.res = res; p.act = act;
     const bool sx = x3 && g.wx3;
     p.w = sx ? g.wx3 : g.w; p.x3 = sx;
     return conv(e, p);
@@ -671,13 +671,9 @@ int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, float*
         RET(gemm(f.pw2, tmp, oth, H, H, cur));
         std::swap(cur, oth);
       }
-      // FeedForwardModule (:294-301): LayerNorm, Linear, Swish, Linear; x + factor * ff(x) with the factor folded into the weights
+      // FeedForwardModule (:294-301): LayerNorm, Linear + Swish (GEMM epilogue), Linear; x + factor * ff(x) with the factor folded into the weights
       RET(ln(cur, tmp, f.ff_lng[half], f.ff_lnb[half], nullptr));
-      RET(gemm(f.ff_a[half], tmp, hid, H, F, nullptr));
-      {
-        ProfScope ps(e, "misc", 0, 8.0 * B * N * F);
-        KCHK(e, launch_swish(hid, (long long)B * N * F, e->stream));
-      }
+      RET(gemm(f.ff_a[half], tmp, hid, H, F, nullptr, ACT_SWISH));
       RET(gemm(f.ff_b[half], hid, oth, F, H, cur));
       std::swap(cur, oth);
     }

@@ -7,7 +7,7 @@
 
 namespace e2etts {
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_SWISH = 4 /* v * sigmoid(v), Conformer FFN */ };
 
 // out[b, t, n] = epilogue( sum_{j < KW} sum_{c < Cin} f(in[b, t - pad + j*dil, c]) * w[n, j*Cin + c] )
 // "same" 1-D convolution as an implicit GEMM on the fp32 MFMA (M = time, N = Cout, K = KW*Cin);
@@ -108,7 +108,6 @@ const char* launch_istft(const float* q, int ldq, float* specphase, float* ri, f
                          int hop, hipStream_t s);
 
 // Conformer block pieces (reference U/blocks/conformer.py:273-304, 443-481; U/blocks/utils.py:196-219)
-const char* launch_swish(float* x, long long n, hipStream_t s);                                     // x *= sigmoid(x), in place
 const char* launch_glu(const float* in, float* out, long long rows, int C, hipStream_t s);          // [rows, 2C] -> [rows, C]
 // depthwise conv (k taps, zero "same" padding over [0, N), w [k][C], BatchNorm folded into w / bias) + Swish; channels-last
 const char* launch_dwconv_swish(const float* in, const float* w, const float* bias, float* out, int B, int N, int C, int k, hipStream_t s);

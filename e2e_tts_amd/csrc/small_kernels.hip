@@ -309,15 +309,6 @@ __global__ void reflect_lrelu_kernel(const float4* __restrict__ in, float4* __re
 // ---- Conformer block pieces (reference U/blocks/conformer.py, U/blocks/utils.py:196-219) ----
 __device__ __forceinline__ float swish1(float v) { return v * (1.0f / (1.0f + expf(-v))); }
 
-// x = x * sigmoid(x) in place (Swish between the two Linear layers of FeedForwardModule, conformer.py:294-301)
-__global__ void swish_kernel(float4* __restrict__ x, long long n4) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  float4 v = x[i];
-  v.x = swish1(v.x); v.y = swish1(v.y); v.z = swish1(v.z); v.w = swish1(v.w);
-  x[i] = v;
-}
-
 // GLU over channels (conformer.py:472, utils.py:217-219): out[row, c] = in[row, c] * sigmoid(in[row, C + c])
 __global__ void glu_kernel(const float4* __restrict__ in, float4* __restrict__ out, long long rows, int c4) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -576,12 +567,6 @@ const char* launch_reflect_lrelu(const float* in, float* out, int B, long long n
   hipLaunchKernelGGL(reflect_lrelu_kernel, dim3((unsigned)((items + 255) / 256), B), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), n, C / 4, slope);
   return CHECK_LAUNCH("reflect_lrelu");
-}
-
-const char* launch_swish(float* x, long long n, hipStream_t s) {
-  if (!x || n <= 0 || n % 4 || ((uintptr_t)x & 15)) return "swish: bad buffer";
-  hipLaunchKernelGGL(swish_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<float4*>(x), n / 4);
-  return CHECK_LAUNCH("swish");
 }
 
 const char* launch_glu(const float* in, float* out, long long rows, int C, hipStream_t s) {

@@ -78,11 +78,12 @@ def test_tts_from_checkpoint_files_matches_oracle(tmp_path):
             assert 0.3 * (n1 - silence) <= n2 - silence <= 0.7 * (n1 - silence)
 
 
-def test_model_mirrors_match_reference_fixture():
+@pytest.mark.parametrize("name", ["tiny_b3", "tiny_cf_b3"])  # FFT blocks / Conformer blocks (config-selected, U/model.py:24-27)
+def test_model_mirrors_match_reference_fixture(name):
     import torch
     from e2e_tts_amd.models import HifiGan, UnsupervisedFastSpeech2
-    g = load_golden("tiny_b3")
-    cfg, ac, voc = states_for(g, "tiny_b3")
+    g = load_golden(name)
+    cfg, ac, voc = states_for(g, name)
     m = UnsupervisedFastSpeech2(n_symbols=131, n_speakers=4, n_channels=80, config=cfg["models"]["fastspeech2"],
                                 stats=cfgmod.DEFAULT_STATS)
     m.load_state_dict(sw.to_torch(ac))

@@ -199,6 +199,54 @@ def test_error_paths():
         eng.load_weights(np.zeros(64, np.uint8))                                  # not a blob
 
 
+@pytest.mark.parametrize("name", ["tiny_b3", "tiny_cf_b3"])
+def test_steady_state_allocates_nothing_and_repeats_exactly(name):
+    """A serving loop: after the first call of a shape the workspace is reused (device_bytes constant) and every repetition
+    returns the same PCM bit for bit -- the whole padded array without ragged compute, every valid sample with it (rows past an
+    utterance's end are skipped there and hold whatever the workspace held)."""
+    g = load_golden(name)
+    cfg, eng = engine_for(g, name)
+    eng.set_precision("bf16x3")
+    hop = cfg["audio"]["stft"]["hop_length"]
+    spk = np.array([int(g["speaker"])], np.int64)
+    try:
+        for ragged in (False, True):
+            eng.set_ragged(ragged)
+            first, ml, T = eng.synthesize(g["ids"], g["lens"], spk)
+            eng.sync()
+            bytes0 = eng.device_bytes()
+            for _ in range(8):
+                again, ml2, T2 = eng.synthesize(g["ids"], g["lens"], spk)
+                assert T2 == T and (ml2 == ml).all()
+                if ragged:
+                    for b, n in enumerate(ml * hop):
+                        np.testing.assert_array_equal(again[b, :n], first[b, :n])
+                else:
+                    np.testing.assert_array_equal(again, first)
+            eng.sync()
+            assert eng.device_bytes() == bytes0
+    finally:
+        eng.set_ragged(True)
+
+
+def test_conformer_rejects_sequences_beyond_the_position_table():
+    """Conformer attention needs pos_proj(table) rows for every position: a sequence longer than the shipped regenerated table
+    is an error, not an out-of-bounds read."""
+    from e2e_tts_amd import packer, synth_weights as sw
+    from e2e_tts_amd._lib import Engine
+    cfg = cfgmod.tiny_config()
+    cfg["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"
+    dims = cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4, pos_table_rows=96)
+    eng = Engine(dims, 0)
+    eng.load_weights(packer.pack(dims, sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, mode="varied"), sw.make_vocoder_state(cfg)))
+    rng = np.random.Generator(np.random.PCG64(3))
+    ok = rng.integers(4, 131, size=(1, 80)).astype(np.int64)        # 80 > max_seq_len = 60: regenerated table, fits in 96 rows
+    with pytest.raises(ValueError):                                 # the decoder's T (several frames per phoneme) does not
+        eng.acoustic(ok, np.array([80], np.int64), np.array([0], np.int64))
+    with pytest.raises(ValueError):
+        eng.acoustic(rng.integers(4, 131, size=(1, 100)).astype(np.int64), np.array([100], np.int64), np.array([0], np.int64))
+
+
 @pytest.mark.parametrize("name", ["tiny_b3", "tiny_ctl", "full_b3", "c3_mixed", "tiny_cf_b3"])
 def test_ragged_synthesize_is_bit_identical_on_valid_samples(name):
     """synthesize() with ragged compute (skip what no valid sample depends on) vs the full padded batch: same PCM on every

@@ -89,6 +89,8 @@ struct e2etts_engine {
   std::string err;
   size_t dev_bytes = 0;
 
+  std::vector<DevBuf*> owned;  // every buffer ensure() has ever allocated (members of this struct); e2etts_destroy frees them
+
   // weights
   DevBuf blob;
   std::map<std::string, std::pair<const float*, uint64_t>> tensors;
@@ -175,6 +177,7 @@ int ensure(e2etts_engine* e, DevBuf& b, size_t bytes) {
     b.p = nullptr;
     b.cap = 0;
   }
+  if (std::find(e->owned.begin(), e->owned.end(), &b) == e->owned.end()) e->owned.push_back(&b);
   size_t want = (bytes + 255) & ~size_t(255);
   if (hipMalloc(&b.p, want) != hipSuccess) {
     b.p = nullptr;
@@ -1147,11 +1150,7 @@ void e2etts_destroy(e2etts_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
-  DevBuf* bufs[] = {&e->blob, &e->ids, &e->lens64, &e->lens32, &e->spk, &e->xa, &e->xb, &e->xs, &e->xp, &e->tmp, &e->qkv, &e->att,
-                    &e->hid, &e->p1, &e->p2, &e->logd, &e->durf, &e->cum, &e->mel64, &e->mel32, &e->posbuf, &e->ppred, &e->epred,
-                    &e->pidx, &e->eidx, &e->dx, &e->dxb, &e->mel, &e->melpost, &e->pn1, &e->pn2, &e->encout, &e->melin, &e->v0,
-                    &e->v1, &e->v2, &e->v3, &e->wav, &e->pcm, &e->st_carry, &e->st_win, &e->actbuf};
-  for (DevBuf* b : bufs)
+  for (DevBuf* b : e->owned)  // registered by ensure(): no hand-kept list to fall behind when a buffer is added
     if (b->p) (void)hipFree(b->p);
   for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);

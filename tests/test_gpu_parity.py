@@ -229,6 +229,38 @@ def test_steady_state_allocates_nothing_and_repeats_exactly(name):
         eng.set_ragged(True)
 
 
+def test_destroy_releases_all_device_memory():
+    """Every workspace buffer -- including the ones only the iSTFT tail and the Conformer blocks allocate -- is returned by
+    e2etts_destroy (free device memory before the first engine == after the last one, within allocator granularity)."""
+    import torch
+    from e2e_tts_amd import packer, synth_weights as sw
+    from e2e_tts_amd._lib import Engine
+    rng = np.random.Generator(np.random.PCG64(5))
+    ids = rng.integers(4, 131, size=(2, 24)).astype(np.int64)
+    lens = np.array([24, 13], np.int64)
+    spk = np.array([1], np.int64)
+
+    def one(vocoder, blocks):
+        cfg = cfgmod.tiny_config()
+        cfg["models"]["fastspeech2"]["building_block"]["block_type"] = blocks
+        dims = cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4, vocoder=vocoder)
+        eng = Engine(dims, 0)
+        eng.load_weights(packer.pack(dims, sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, mode="varied"),
+                                     sw.make_vocoder_state(cfg, vocoder=vocoder)))
+        pcm, ml, T = eng.synthesize(ids, lens, spk)
+        assert eng.device_bytes() > 0 and pcm.shape[1] == T * 256
+        eng.close()
+
+    one("hifigan", "transformer")   # warm-up: the HIP runtime's own first-use allocations
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for vocoder, blocks in (("istft", "conformer"), ("hifigan", "conformer"), ("istft", "transformer")):
+        one(vocoder, blocks)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < (4 << 20), f"{(free0 - free1) / 2**20:.1f} MiB not returned"
+
+
 def test_conformer_rejects_sequences_beyond_the_position_table():
     """Conformer attention needs pos_proj(table) rows for every position: a sequence longer than the shipped regenerated table
     is an error, not an out-of-bounds read."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 counter passes of `bench.py` into profiles/<round>/pmc_summary.md and profiles/pmc_traffic.json.
 
-    python tools/pmc_summary.py gpurun_out/prof profiles/r1 [--title "..."]
+    python tools/pmc_summary.py gpurun_out/prof profiles/r1 [--title "..."] [--name other.md]
 
 reads every `*counter_collection.csv` and `*kernel_stats.csv` below the first directory.  Passes expected (separate runs of
 `rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`, counters only,
@@ -31,7 +31,9 @@ def kernel_class(name: str):
     m = re.search(r"resblock_pair_kernel<\d+, (\d+)", name)
     if m:
         return "resblock_pair_" + m.group(1)
-    for key, cls in (("attention_x3_kernel", "attention_x3"), ("attention_kernel", "attention"), ("layernorm_kernel", "layernorm"), ("conv_post_kernel", "conv_post")):
+    for key, cls in (("rel_attention_kernel", "rel_attention"), ("attention_x3_kernel", "attention_x3"), ("attention_kernel", "attention"),
+                     ("layernorm_kernel", "layernorm"), ("conv_post_kernel", "conv_post"), ("dwconv_swish_kernel", "dwconv_swish"),
+                     ("glu_kernel", "glu")):
         if key in name:
             return cls
     return None
@@ -40,6 +42,9 @@ def kernel_class(name: str):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     title = sys.argv[4] if len(sys.argv) > 4 and sys.argv[3] == "--title" else "PMC summary"
+    # --name FILE.md: write the table under that name and leave profiles/pmc_traffic.json (bench.py's `roofline.traffic` source, which
+    # belongs to the headline workload) alone -- for side workloads such as `bench.py --blocks conformer`
+    name = sys.argv[sys.argv.index("--name") + 1] if "--name" in sys.argv else None
     counters = defaultdict(lambda: defaultdict(float))   # class -> counter -> sum over dispatches
     ndisp = defaultdict(lambda: defaultdict(int))        # class -> counter -> dispatches seen
     dur_ns = defaultdict(float)
@@ -93,10 +98,11 @@ def main():
         if hbm is not None:
             entry["hbm_bytes_per_launch"] = hbm
         traffic[cls] = entry
-    with open(os.path.join(dst, "pmc_summary.md"), "w") as fh:
+    with open(os.path.join(dst, name or "pmc_summary.md"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
-    with open(os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_traffic.json"), "w") as fh:
-        json.dump(traffic, fh, indent=1)
+    if name is None:
+        with open(os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_traffic.json"), "w") as fh:
+            json.dump(traffic, fh, indent=1)
     print("\n".join(lines))
 
 

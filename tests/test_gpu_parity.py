@@ -402,12 +402,15 @@ def test_istft_engine_end_to_end_ragged():
     assert np.abs(full.astype(np.int32)).max() > 10
 
 
-def test_full_size_batch_is_deterministic_and_linear_in_batch():
-    """Size-independent properties at the bench size (B = 32, L = 128 -> T = 768, default model): two runs give the same bits, and
-    an utterance's PCM does not depend on WHICH other utterances share the (equally long) batch -- rows are independent."""
+@pytest.mark.parametrize("blocks", ["transformer", "conformer"])
+def test_full_size_batch_is_deterministic_and_linear_in_batch(blocks):
+    """Size-independent properties at the bench size (B = 32, L = 128 -> T = 768, default model, FFT or Conformer blocks): two runs
+    give the same bits, and an utterance's PCM does not depend on WHICH other utterances share the (equally long) batch -- rows are
+    independent, also across the tile shapes the launches pick for 32 and for 5 utterances."""
     from e2e_tts_amd import synth_weights as sw
     from e2e_tts_amd.runtime import engine_from_states
     cfg = cfgmod.default_config()
+    cfg["models"]["fastspeech2"]["building_block"]["block_type"] = blocks
     ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=1234, mode="fixed", frames_per_phoneme=6)
     voc = sw.make_vocoder_state(cfg, seed=4321)
     eng = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)

@@ -96,16 +96,22 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
 //        engine).  The scalar epilogue for odd shapes lives in instantiations of its own: next to the vector one, its
 //        conditional loads made hipcc drain vmcnt(0) after every barrier of the main loop, i.e. wait for the weight
 //        tile it had just requested before issuing the first MFMA.
-template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG>
+// CPI > 0 (KW == 1 launches on the fragment path, Cin a multiple of 32 CPI): a work item stages CPI 32-channel chunks at once, as
+//        CPI planes of the slab, and the loop walks them like taps.  A plain Linear has ONE tap per chunk, i.e. two workgroup
+//        barriers and a staging pass per 24 MFMAs of a wave; with CPI planes it is one per 24 CPI.  Same chunk order, same bits.
+template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
   static_assert(!BFRAG || MODE != 0, "fragment-order weights exist for the bf16 modes only");
+  constexpr bool K1 = CPI > 0;
+  static_assert(!K1 || BFRAG, "multi-chunk items exist on the fragment path only");
   constexpr bool X3 = MODE != 0;
   constexpr bool SPLIT = MODE == 1;
   constexpr int NWN = BN / WN;
   constexpr int MT = WM / 32, NT = WN / 32;
   static_assert((BM / WM) * NWN == 4, "4 wavefronts per workgroup");
   constexpr int BROWS = BN / 32;                      // weight-tile rows staged per thread
-  constexpr int AROWS = (BM + MAX_HALO + 31) / 32;    // slab rows staged per thread (upper bound)
+  constexpr int AROWS1 = K1 ? BM / 32 : (BM + MAX_HALO + 31) / 32;  // slab rows staged per thread and plane (upper bound)
+  constexpr int AROWS = AROWS1 * (K1 ? CPI : 1);
   constexpr int ELD = WN + 4;                         // epilogue patch row stride (floats)
   static_assert(4 * 16 * ELD <= BM * LDK, "epilogue patches must fit in the slab");
 
@@ -132,8 +138,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   const float* in_b = p.in + (long long)b * p.in_bs;
   const int nchunk = (p.Cin + BK - 1) / BK;
   const int KC = X3 ? p.KW * nchunk * BK : p.KW * p.Cin;  // X3 weights: [Cout][KW][nchunk][32 words], chunk-padded
-  const int nitem = ntile * nchunk;
-  const int niter = nitem * p.KW;
+  const int ntap = K1 ? CPI : p.KW;             // loop steps per work item: taps, or the planes of a K1 item
+  const int nci = K1 ? nchunk / CPI : nchunk;   // work items per tile
+  const int nitem = ntile * nci;
+  const int niter = nitem * ntap;
+  const int plane = arows * LDK;                // floats per slab plane (K1)
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -192,9 +201,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   }
   w_all_ok = n0 + BN <= p.Cout;               // uniform: no row of the weight tile needs zeroing
   const bool ragged = (p.Cin % BK) != 0;      // uniform: the last chunk is partial (fp32 layout only)
-  int avoff[AROWS];
+  int avoff[AROWS1];
 #pragma unroll
-  for (int i = 0; i < AROWS; ++i) avoff[i] = ((lrow + i * 32) * p.in_ld + lc4) * 4;
+  for (int i = 0; i < AROWS1; ++i) avoff[i] = ((lrow + i * 32) * p.in_ld + lc4) * 4;
   const int cmax = p.Cin - 4;  // Cin % 4 == 0: last float4 of a row
   bool b_cok = true, a_cok = true, b_mask = false, a_edge = false;
   int a_tbase = 0;
@@ -221,11 +230,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
     for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4*>(dst + (lrow + i * 32) * LDK + lc4) = breg[i];
   };
   auto load_a = [&](int tile, int chunk) {
+    if constexpr (K1) {  // CPI whole chunks (Cin % (32 CPI) == 0, checked by the launcher); only the last tile can cross T
+      a_cok = true;
+      a_tbase = tile * BM - p.pad;
+      a_edge = a_tbase < 0 || a_tbase + BM > p.T;
+#pragma unroll
+      for (int pl = 0; pl < CPI; ++pl) {
+        const int ch = chunk * CPI + pl;
+        if (!a_edge) {
+          const int soff = (a_tbase * p.in_ld + ch * BK) * 4;
+#pragma unroll
+          for (int i = 0; i < AROWS1; ++i)
+            areg[pl * AROWS1 + i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, avoff[i], soff, 0));
+        } else {
+#pragma unroll
+          for (int i = 0; i < AROWS1; ++i) {
+            const int t = min(max(a_tbase + lrow + i * 32, 0), p.T - 1);
+            areg[pl * AROWS1 + i] =
+                __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (t * p.in_ld + ch * BK + lc4) * 4, 0, 0));
+          }
+        }
+      }
+      return;
+    }
     const int c = chunk * BK + lc4;
     a_cok = c < p.Cin;
     a_tbase = tile * BM - p.pad;
     // interior slab of a full chunk: every row and channel exists -> scalar offset, invariant lane offsets
-    a_edge = a_tbase < 0 || a_tbase + AROWS * 32 > p.T || (ragged && chunk == nchunk - 1);
+    a_edge = a_tbase < 0 || a_tbase + AROWS1 * 32 > p.T || (ragged && chunk == nchunk - 1);
     if (!a_edge) {
       const int soff = (a_tbase * p.in_ld + chunk * BK) * 4;
 #pragma unroll
@@ -243,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   auto store_a = [&]() {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int r = lrow + i * 32;
+      const int r = lrow + (K1 ? i % AROWS1 : i) * 32;
+      float* As = smem + (K1 ? (i / AROWS1) * plane : 0);  // plane of this register (shadows the slab base)
       float4 v = areg[i];
       if (a_edge) {
         const int t = a_tbase + r;
@@ -408,10 +441,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 #endif
   for (int it = 0; it < niter; ++it) {
     DIAG_STAMP(ta);
-    const bool last_tap = j == p.KW - 1;
-    const bool tile_done = last_tap && chunk == nchunk - 1;
+    const bool last_tap = j == ntap - 1;
+    const bool tile_done = last_tap && chunk == nci - 1;
     const bool more_items = !(tile_done && tl == ntile - 1);
-    const int nchk = chunk + 1 == nchunk ? 0 : chunk + 1;
+    const int nchk = chunk + 1 == nci ? 0 : chunk + 1;
     // Weight tile first, slab second: hipcc reuses the registers of earlier loads for address arithmetic and then
     // waits (vmcnt) for whatever is in flight -- with the slab loads issued first that was a full HBM round trip.
     if constexpr (!BFRAG) {
@@ -428,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
     // Between two waves of a SIMD the one streaming MFMAs starves the other's vector issue (measured: ~1 MFMA
     // slot per VALU / VMEM / LDS instruction).  Staging code therefore runs at raised priority, MFMA blocks at 0.
     __builtin_amdgcn_s_setprio(0);
-    const float* a_base = As + (wm * WM + li + j * p.dil) * LDK + lh * 4;
+    const float* a_base = K1 ? As + j * plane + (wm * WM + li) * LDK + lh * 4 : As + (wm * WM + li + j * p.dil) * LDK + lh * 4;
     const float* b_base = Bs + cur * (BN * LDK) + (wn * WN + li) * LDK + lh * 4;
     if constexpr (X3) {
       // lane (row li, half lh) holds k = 16 s + 8 lh .. + 7 of its row: one 16-byte read per operand half
@@ -465,8 +498,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
         if constexpr (BFRAG) {  // fragments of this k-step are consumed: request them for the next iteration (one k-step of cover)
           // unconditional (the very last iteration re-requests fragments nobody uses): with a branch around them
           // hipcc has to assume "first k-step requested, second not" and waits for all eight loads at the loop head
-          if (!last_tap) load_frag(chunk, j + 1, ks);
-          else load_frag(nchk, 0, ks);
+          if constexpr (K1) {  // plane j of item `chunk` is 32-channel chunk chunk * CPI + j of the (single) tap
+            load_frag(last_tap ? nchk * CPI : chunk * CPI + j + 1, 0, ks);
+          } else {
+            if (!last_tap) load_frag(chunk, j + 1, ks);
+            else load_frag(nchk, 0, ks);
+          }
         }
       }
     } else {
@@ -520,12 +557,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG>
+template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0>
 const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   const int halo = p.dil * (p.KW - 1);
   static const int lds_pad = getenv("E2ETTS_LDS_PAD") ? atoi(getenv("E2ETTS_LDS_PAD")) : 0;  // tuning aid: occupancy experiments
-  const size_t lds = (size_t)((BM + halo) * LDK + (BFRAG ? 0 : 2 * BN * LDK)) * sizeof(float) + (BFRAG ? lds_pad : 0);
-  if (lds > 64 * 1024) return "conv_gemm: LDS tile exceeds 64 KiB";
+  const size_t lds = (size_t)((BM + halo) * LDK * (CPI > 0 ? CPI : 1) + (BFRAG ? 0 : 2 * BN * LDK)) * sizeof(float) + (BFRAG ? lds_pad : 0);
+  if (lds > 80 * 1024) return "conv_gemm: LDS tile exceeds 80 KiB";
+  if (lds > 64 * 1024) {  // the multi-chunk Linear form: opt in once per instantiation (two workgroups per CU still fit)
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (attr != hipSuccess) return "conv_gemm: cannot raise the dynamic LDS limit";
+  }
   const int mtiles = (p.T + BM - 1) / BM;
   const int ntiles = (p.Cout + BN - 1) / BN;
   // Persistent over M: enough workgroups for ~8 per CU, each walking up to 8 consecutive tiles.
@@ -535,7 +577,7 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
   if (tpb > mtiles) tpb = mtiles;
   dim3 grid((mtiles + tpb - 1) / tpb, ntiles, p.B);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG>), grid, dim3(256), lds, s, p, tpb);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI>), grid, dim3(256), lds, s, p, tpb);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
 }
 
@@ -544,6 +586,14 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int MODE>
 const char* launch_cfg(const ConvParams& p, hipStream_t s) {
   if constexpr (MODE != 0 && BN == 128) {
+    // plain Linear layers (q | k | v, fc, the k = 1 FFN conv, every Conformer GEMM): several chunks per work item
+    static const int cpi_env = getenv("E2ETTS_K1_CPI") ? atoi(getenv("E2ETTS_K1_CPI")) : 4;  // tuning aid: 0 = off, 2, 4
+    if constexpr (BM == 128) {
+      if (p.wfrag && p.KW == 1 && !p.accumulate && cpi_env > 0) {
+        if (cpi_env >= 4 && p.Cin % (4 * BK) == 0) return launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, true, 4>(p, s);
+        if (p.Cin % (2 * BK) == 0) return launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, true, 2>(p, s);
+      }
+    }
     if (p.wfrag)
       return p.accumulate ? launch_cfg_impl<BM, BN, WM, WN, MODE, true, true, true>(p, s)
                           : launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, true>(p, s);

@@ -588,7 +588,7 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
   if constexpr (MODE != 0 && BN == 128) {
     // plain Linear layers (q | k | v, fc, the k = 1 FFN conv, every Conformer GEMM): several chunks per work item
     static const int cpi_env = getenv("E2ETTS_K1_CPI") ? atoi(getenv("E2ETTS_K1_CPI")) : 4;  // tuning aid: 0 = off, 2, 4
-    if constexpr (BM == 128) {
+    if constexpr (BM == 128 || BM == 64) {
       if (p.wfrag && p.KW == 1 && !p.accumulate && cpi_env > 0) {
         if (cpi_env >= 4 && p.Cin % (4 * BK) == 0) return launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, true, 4>(p, s);
         if (p.Cin % (2 * BK) == 0) return launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, true, 2>(p, s);
@@ -602,6 +602,21 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
                       : launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, false>(p, s);
 }
 
+// Tile choice for Cout > 64.  few: so few rows (small batches, the B = 1 latency path, the encoder) that 128 x 128 tiles would leave
+// CUs idle -> 64 x 64.  half: on the fragment path, a 128 x 128 grid whose last round of workgroups (2 per CU = 512 at a time) is
+// mostly empty -- 576 tiles for a 24576 x 384 Linear are one full round and an eighth of a second -- runs as 64 x 128 tiles: twice
+// the workgroups at half the work, e.g. 3 half-rounds instead of 2 full ones.  Same per-wave MFMA : fragment ratio (MT = 2).
+bool few_rows(const ConvParams& p) {
+  return p.Cout > 64 && (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B < 2 * 256;
+}
+bool half_rows(const ConvParams& p) {
+  static const bool on = !(getenv("E2ETTS_HALF_ROWS") && atoi(getenv("E2ETTS_HALF_ROWS")) == 0);  // tuning aid
+  if (!on || !p.x3 || !p.wfrag || p.accumulate || p.Cout <= 64 || few_rows(p)) return false;
+  const long long wg = (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B, slots = 2 * 256;
+  const long long r128 = (wg + slots - 1) / slots, r64 = (2 * wg + slots - 1) / slots;
+  return 0.5 * 1.06 * (double)r64 < (double)r128;
+}
+
 bool epilogue_vec_ok(const ConvParams& p) {
   return (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && ((p.out_bs & 3) == 0) && (((uintptr_t)p.out & 15) == 0) &&
          (!p.res || ((p.res_ld % 4 == 0) && ((p.res_bs & 3) == 0) && (((uintptr_t)p.res & 15) == 0))) &&
@@ -613,6 +628,17 @@ bool epilogue_vec_ok(const ConvParams& p) {
 #ifdef E2ETTS_DIAG
 void conv_gemm_read_diag(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_diag), sizeof(g_conv_diag)); }
 #endif
+
+// the profile class of a launch = the tile configuration launch_conv_gemm picks for it (vector-epilogue shapes)
+const char* conv_gemm_class(const ConvParams& p) {
+  if (p.x3) {
+    if (few_rows(p)) return "conv_x3_64x64";
+    if (half_rows(p)) return "conv_x3_64x128";
+    return p.Cout > 64 ? "conv_x3_128x128" : (p.Cout > 32 ? "conv_x3_256x64" : "conv_x3_256x32");
+  }
+  if (p.Cout > 64) return few_rows(p) ? "conv_gemm_64x64" : "conv_gemm_128x128";
+  return p.Cout > 32 ? "conv_gemm_256x64" : "conv_gemm_256x32";
+}
 
 double conv_gemm_flops(const ConvParams& p) { return 2.0 * p.B * (double)p.T * p.Cout * p.KW * p.Cin; }
 
@@ -643,15 +669,17 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
     return launch_cfg_impl<128, 128, 64, 64, 0, false, false, false>(p, s);
   }
   // few rows (small batches, the B = 1 latency path): 64 x 64 tiles give 4x the workgroups of 128 x 128
-  const bool few = p.Cout > 64 && (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B < 2 * 256;
+  const bool few = few_rows(p), half = half_rows(p);
   if (p.x3 == 1) {
     if (few) return launch_cfg<64, 64, 32, 32, 1>(p, s);
+    if (half) return launch_cfg<64, 128, 64, 32, 1>(p, s);
     if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 1>(p, s);
     if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 1>(p, s);
     return launch_cfg<256, 32, 64, 32, 1>(p, s);
   }
   if (p.x3 == 2) {
     if (few) return launch_cfg<64, 64, 32, 32, 2>(p, s);
+    if (half) return launch_cfg<64, 128, 64, 32, 2>(p, s);
     if (p.Cout > 64) return launch_cfg<128, 128, 64, 64, 2>(p, s);
     if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 2>(p, s);
     return launch_cfg<256, 32, 64, 32, 2>(p, s);

@@ -259,13 +259,6 @@ int prof_collect(e2etts_engine* e) {
     if (_m) return (e)->fail(E2ETTS_EINVAL, "%s", _m);             \
   } while (0)
 
-const char* conv_cfg_name(const ConvParams& p) {
-  const bool few = p.Cout > 64 && (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B < 512;
-  if (p.x3) return few ? "conv_x3_64x64" : (p.Cout > 64 ? "conv_x3_128x128" : (p.Cout > 32 ? "conv_x3_256x64" : "conv_x3_256x32"));
-  if (p.Cout > 64) return few ? "conv_gemm_64x64" : "conv_gemm_128x128";
-  return p.Cout > 32 ? "conv_gemm_256x64" : "conv_gemm_256x32";
-}
-
 // One conv / linear launch.  alg_scale < 1 when part of the packed weight is structural zeros
 // (the polyphase upsampler) so that the recorded FLOPs stay the algorithmic ones.
 int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
@@ -285,7 +278,7 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
   if (fine && e->prof_on)
     snprintf(fname, sizeof fname, "%s %d>%d k%d d%d r%lld%s%s", p.x3 ? "x3" : "f32", p.Cin, p.Cout, p.KW, p.dil,
              (long long)p.B * p.T, p.res ? "+r" : "", p.accumulate ? "+a" : "");
-  ProfScope ps(e, fine && e->prof_on ? fname : conv_cfg_name(p), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
+  ProfScope ps(e, fine && e->prof_on ? fname : conv_gemm_class(p), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
   KCHK(e, launch_conv_gemm(p, e->stream));
   return E2ETTS_OK;
 }

@@ -36,6 +36,7 @@ struct ConvParams {
 };
 // returns nullptr on success, else a static error string
 const char* launch_conv_gemm(const ConvParams& p, hipStream_t s);
+const char* conv_gemm_class(const ConvParams& p);  // profile class = the tile configuration the launch will use
 double conv_gemm_flops(const ConvParams& p);
 double conv_gemm_bytes(const ConvParams& p);
 

@@ -291,7 +291,13 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
               v.x = v.x / p.out_div; v.y = v.y / p.out_div; v.z = v.z / p.out_div; v.w = v.w / p.out_div;
             }
           }
-          if (t < t_end) *reinterpret_cast<float4*>(out_b + (long long)t * C + ecol) = v;
+          // streaming store: this kernel never reads the tile back, and keeping it out of the way leaves the x rows (slab halo of the
+          // neighbour tile, residual re-read) in L2
+          if (t < t_end) {
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const f32x4_t nv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(nv, reinterpret_cast<f32x4_t*>(out_b + (long long)t * C + ecol));
+          }
         }
       }
     }

@@ -3,6 +3,8 @@ library is missing or no GPU is visible, construction raises."""
 from __future__ import annotations
 
 import ctypes as C
+import functools
+import threading
 import os
 from typing import Optional
 
@@ -112,10 +114,26 @@ def _addr(x) -> Optional[int]:
     raise TypeError(f"cannot take the address of {type(x)}")
 
 
+def _locked(fn):
+    """Run a method under the engine's re-entrant lock.  Every C entry point takes the engine's mutex, but several results are
+    RESIDENT (`synthesize` then `fetch_pcm`, `acoustic` then `fetch_mel` / `vocoder(None)`): a method that is a sequence of C calls,
+    and the error text read after a failing one, must not interleave with another thread's calls on the same engine."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with self.lock:
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class Engine:
-    """One GPU, one stream, one set of weights.  Thin, typed wrapper over the C ABI."""
+    """One GPU, one stream, one set of weights.  Thin, typed wrapper over the C ABI.
+
+    Thread safety: every method is atomic with respect to the other methods of the same Engine (`self.lock`, an RLock).  A caller that
+    relies on resident results ACROSS methods from several threads -- `acoustic()` ... `fetch_mel()` ... `vocoder(None, ...)` -- holds
+    `with engine.lock:` around the sequence, as the model mirrors do.  Distinct engines are independent."""
 
     def __init__(self, dims: EngineDims, device: int = 0):
+        self.lock = threading.RLock()
         self.lib = load_library()
         self.dims = dims
         self._h = C.c_void_p()
@@ -151,12 +169,14 @@ class Engine:
         raise RuntimeError(msg)
 
     # ---- weights
+    @_locked
     def load_weights(self, blob) -> None:
         """blob: uint8 numpy array (host) or uint8 torch tensor (host / HBM, e.g. after a RCCL broadcast)."""
         n = blob.nbytes if isinstance(blob, np.ndarray) else blob.numel() * blob.element_size()
         self._check(self.lib.e2etts_load_weights(self._h, _addr(blob), n), "e2etts_load_weights")
 
     # ---- acoustic model
+    @_locked
     def acoustic(self, ids, lens, speaker, d_control=1.0, p_control=1.0, e_control=1.0, want=("dur", "mel_lens")):
         """ids [B, L] int64, lens [B] int64, speaker [1 or B] int64 (numpy or torch, host or device).
         Returns dict with T and the requested host arrays."""
@@ -184,23 +204,27 @@ class Engine:
         out["B"] = B
         return out
 
+    @_locked
     def fetch_mel(self, B: int, T: int, mel=True, mel_post=True, out_mel=None, out_mel_post=None):
         m = out_mel if out_mel is not None else (np.empty((B, T, self.dims.n_mel), np.float32) if mel else None)
         mp = out_mel_post if out_mel_post is not None else (np.empty((B, T, self.dims.n_mel), np.float32) if mel_post else None)
         self._check(self.lib.e2etts_fetch_mel(self._h, _addr(m), _addr(mp)), "e2etts_fetch_mel")
         return m, mp
 
+    @_locked
     def fetch_tap(self, which: str, shape) -> np.ndarray:
         out = np.empty(shape, np.float32)
         self._check(self.lib.e2etts_fetch_tap(self._h, which.encode(), _addr(out), out.size), "e2etts_fetch_tap")
         return out
 
+    @_locked
     def fetch_tap_into(self, which: str, out) -> None:
         """Like fetch_tap, into a caller buffer (numpy array or torch tensor, host or HBM)."""
         n = out.size if isinstance(out, np.ndarray) else out.numel()
         self._check(self.lib.e2etts_fetch_tap(self._h, which.encode(), _addr(out), n), "e2etts_fetch_tap")
 
     # ---- vocoder
+    @_locked
     def vocoder(self, mel, B: int, T: int, channels_first=True, wav=True, pcm=False, out_wav=None, out_pcm=None):
         """mel: [B, n_mel, T] (channels_first) or [B, T, n_mel], or None for the resident mel_post."""
         n = B * T * self.dims.hop_length
@@ -212,6 +236,7 @@ class Engine:
         return w, p
 
     # ---- end to end
+    @_locked
     def synthesize(self, ids, lens, speaker, d_control=1.0, p_control=1.0, e_control=1.0, fetch_pcm=True,
                    out_pcm=None, out_mel_lens=None):
         """One batch of TTS.inference: returns (pcm [B, T*hop] int16 or None, mel_lens [B], T)."""
@@ -231,11 +256,13 @@ class Engine:
             self._check(self.lib.e2etts_fetch_pcm(self._h, _addr(pcm), pcm.size), "e2etts_fetch_pcm")
         return pcm, mel_lens, T.value
 
+    @_locked
     def fetch_wav(self, B: int, T: int) -> np.ndarray:
         w = np.empty((B, T * self.dims.hop_length), np.float32)
         self._check(self.lib.e2etts_fetch_wav(self._h, _addr(w), w.size), "e2etts_fetch_wav")
         return w
 
+    @_locked
     def set_precision(self, vocoder: str = "bf16x3", decoder: Optional[str] = None):
         """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, the default) for the vocoder and for the
         decoder + mel_linear + postnet (defaults to the vocoder's choice).  Encoder / variance adaptor: always fp32."""
@@ -243,10 +270,12 @@ class Engine:
         dec = decoder if decoder is not None else ("bf16x3" if vocoder == "bf16" else vocoder)
         self._check(self.lib.e2etts_set_precision(self._h, modes[vocoder], modes[dec]), "e2etts_set_precision")
 
+    @_locked
     def set_ragged(self, on: bool = True):
         """synthesize(): skip the rows of shorter utterances that no valid sample depends on (default on)."""
         self._check(self.lib.e2etts_set_ragged(self._h, 1 if on else 0), "e2etts_set_ragged")
 
+    @_locked
     def set_fused_resblocks(self, on: bool = True):
         """bf16 modes: each ResBlock conv pair at 32 / 64 / 128 channels as one kernel (default on); results are bit-identical."""
         self._check(self.lib.e2etts_set_fused_resblocks(self._h, 1 if on else 0), "e2etts_set_fused_resblocks")
@@ -275,13 +304,16 @@ class Engine:
             cur = nxt
 
     # ---- profiling
+    @_locked
     def profile_enable(self, on: bool = True):
         self._check(self.lib.e2etts_profile_enable(self._h, 1 if on else 0), "e2etts_profile_enable")
 
+    @_locked
     def profile_filter(self, kernel_class=None):
         """Bracket only launches of this kernel class with events (None: all)."""
         self._check(self.lib.e2etts_profile_filter(self._h, kernel_class.encode() if kernel_class else None), "e2etts_profile_filter")
 
+    @_locked
     def profile_read(self):
         arr = (KernelStat * 256)()
         n = self._check(self.lib.e2etts_profile_read(self._h, arr, 256), "e2etts_profile_read")
@@ -291,6 +323,7 @@ class Engine:
     def device_bytes(self) -> int:
         return int(self.lib.e2etts_device_bytes(self._h))
 
+    @_locked
     def sync(self):
         self._check(self.lib.e2etts_sync(self._h), "e2etts_sync")
 

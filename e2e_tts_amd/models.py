@@ -132,11 +132,12 @@ class UnsupervisedFastSpeech2(_EngineBacked):
         spk = torch.as_tensor(speaker, dtype=torch.int64).reshape(-1).contiguous()
         if max_txt_len is not None and int(max_txt_len) != ids.shape[1]:
             raise ValueError(f"max_txt_len={int(max_txt_len)} != texts.shape[1]={ids.shape[1]}")
-        r = eng.acoustic(ids, lens, spk, d_control, p_control, e_control, want=("dur", "mel_lens"))
-        B, T = r["B"], r["T"]
-        mel = torch.empty((B, T, self.n_channels), dtype=torch.float32, device=dev)
-        mel_post = torch.empty_like(mel)
-        eng.fetch_mel(B, T, out_mel=mel, out_mel_post=mel_post)
+        with eng.lock:  # the mel tensors are the RESIDENT result of this acoustic() call: no other thread's call in between
+            r = eng.acoustic(ids, lens, spk, d_control, p_control, e_control, want=("dur", "mel_lens"))
+            B, T = r["B"], r["T"]
+            mel = torch.empty((B, T, self.n_channels), dtype=torch.float32, device=dev)
+            mel_post = torch.empty_like(mel)
+            eng.fetch_mel(B, T, out_mel=mel, out_mel_post=mel_post)
         dur = torch.from_numpy(r["dur"]).to(dev)
         mel_lens = torch.from_numpy(r["mel_lens"]).to(dev)
         return (mel, mel_post, dur), mel_lens
@@ -230,13 +231,14 @@ class iSTFT(HifiGan):
     def forward(self, x):
         """x [B, 80, T] -> (spec [B, n_fft/2 + 1, F], phase [B, n_fft/2 + 1, F]) on the GPU, F = T * prod(upsample_rates) + 1."""
         torch = _torch()
-        eng, B, T, _ = self._run(x)
         up = 1
         for r in self.config["upsample_rates"]:
             up *= r
-        F, bins = T * up + 1, self.post_n_fft // 2 + 1
-        sp = torch.empty((B, F, 2 * bins), dtype=torch.float32, device=torch.device("cuda", self._device))
-        eng.fetch_tap_into("istft_spec_phase", sp)
+        with self._ensure_engine().lock:  # the tap belongs to this vocoder call
+            eng, B, T, _ = self._run(x)
+            F, bins = T * up + 1, self.post_n_fft // 2 + 1
+            sp = torch.empty((B, F, 2 * bins), dtype=torch.float32, device=torch.device("cuda", self._device))
+            eng.fetch_tap_into("istft_spec_phase", sp)
         sp = sp.transpose(1, 2)
         return sp[:, :bins, :], sp[:, bins:, :]
 

@@ -74,6 +74,10 @@ typedef struct e2etts_config {
                              ffn_k1 = depthwise kernel size */
 } e2etts_config;
 
+/* Threading: every entry point takes the engine's internal mutex, so single calls are safe from any thread and distinct engines are
+ * independent.  Results that stay RESIDENT between calls (e2etts_acoustic -> e2etts_fetch_mel / e2etts_vocoder(NULL, ...),
+ * e2etts_synthesize with pcm_out == NULL -> e2etts_fetch_pcm, taps, the vocoder stream) belong to the last such call: threads sharing one
+ * engine serialise those SEQUENCES themselves (the Python binding holds Engine.lock around them). */
 typedef struct e2etts_engine e2etts_engine;
 
 /* Library / build identification. */

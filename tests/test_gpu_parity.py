@@ -229,6 +229,58 @@ def test_steady_state_allocates_nothing_and_repeats_exactly(name):
         eng.set_ragged(True)
 
 
+def test_engines_are_thread_safe():
+    """calls on one engine are serialised by its mutex, distinct engines are independent (own stream, own workspace).
+    Four threads -- two sharing one engine, two on a second engine -- must each get the PCM a serial call gives (ctypes releases the
+    GIL, so the calls really overlap)."""
+    import threading
+    from e2e_tts_amd import synth_weights as sw
+    from e2e_tts_amd.runtime import engine_from_states
+    cfg = cfgmod.tiny_config()
+    ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=31, mode="varied")
+    voc = sw.make_vocoder_state(cfg, seed=32)
+    engines = [engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0) for _ in range(2)]
+    rng = np.random.Generator(np.random.PCG64(33))
+    jobs = []
+    for k in range(4):
+        lens = rng.integers(5, 40, size=3).astype(np.int64)
+        ids = np.zeros((3, int(lens.max())), np.int64)
+        for b, n in enumerate(lens):
+            ids[b, :n] = rng.integers(4, 131, size=n)
+        jobs.append((engines[k // 2], ids, lens, np.array([k % 4], np.int64)))
+    hop = cfg["audio"]["stft"]["hop_length"]
+
+    def valid(pcm, ml):
+        return [pcm[b, :n].copy() for b, n in enumerate(ml * hop)]
+
+    serial = []
+    for eng, ids, lens, spk in jobs:
+        pcm, ml, _ = eng.synthesize(ids, lens, spk)
+        serial.append(valid(pcm, ml))
+    results, errors = [None] * 4, []
+
+    def work(k):
+        try:
+            eng, ids, lens, spk = jobs[k]
+            for _ in range(5):
+                pcm, ml, _ = eng.synthesize(ids, lens, spk)
+                results[k] = valid(pcm, ml)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(4):
+        for a, b in zip(results[k], serial[k]):
+            np.testing.assert_array_equal(a, b)
+    for e in engines:
+        e.close()
+
+
 def test_destroy_releases_all_device_memory():
     """Every workspace buffer -- including the ones only the iSTFT tail and the Conformer blocks allocate -- is returned by
     e2etts_destroy (free device memory before the first engine == after the last one, within allocator granularity)."""

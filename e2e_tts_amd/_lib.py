@@ -285,7 +285,8 @@ class Engine:
         """Generator: feed an iterable of mel chunks [B, n, n_mel] (numpy / torch, channels-last), yield the waveform (or
         int16 PCM) pieces [B, n_emit * hop] as they become final.  Concatenated along axis 1 they equal
         ``vocoder(whole_mel)`` bit for bit, while HBM use stays bounded by the chunk size."""
-        halo = self._check(self.lib.e2etts_vocoder_stream_begin(self._h, B), "e2etts_vocoder_stream_begin")
+        with self.lock:
+            halo = self._check(self.lib.e2etts_vocoder_stream_begin(self._h, B), "e2etts_vocoder_stream_begin")
         self.stream_halo = halo
         chunks = iter(chunks)
         cur = next(chunks, None)
@@ -293,13 +294,17 @@ class Engine:
             nxt = next(chunks, None)
             n = int(cur.shape[1])
             n_emit = C.c_int(0)
-            self._check(self.lib.e2etts_vocoder_stream_push(self._h, _addr(cur), n, 1 if nxt is None else 0, C.byref(n_emit)),
-                        "e2etts_vocoder_stream_push")
-            if n_emit.value > 0:
-                ns = n_emit.value * self.dims.hop_length
-                out = np.empty((B, ns), np.int16 if want_pcm else np.float32)
-                self._check(self.lib.e2etts_vocoder_stream_fetch(self._h, None if want_pcm else _addr(out),
-                                                                 _addr(out) if want_pcm else None, out.size), "e2etts_vocoder_stream_fetch")
+            out = None
+            with self.lock:  # push + fetch of what it made final are one step (the lock is NOT held across the yield below); the
+                # stream's carried context lives in buffers of its own, so one-shot calls may run between steps
+                self._check(self.lib.e2etts_vocoder_stream_push(self._h, _addr(cur), n, 1 if nxt is None else 0, C.byref(n_emit)),
+                            "e2etts_vocoder_stream_push")
+                if n_emit.value > 0:
+                    ns = n_emit.value * self.dims.hop_length
+                    out = np.empty((B, ns), np.int16 if want_pcm else np.float32)
+                    self._check(self.lib.e2etts_vocoder_stream_fetch(self._h, None if want_pcm else _addr(out),
+                                                                     _addr(out) if want_pcm else None, out.size), "e2etts_vocoder_stream_fetch")
+            if out is not None:
                 yield out
             cur = nxt
 

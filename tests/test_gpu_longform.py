@@ -70,6 +70,13 @@ def test_streaming_equals_one_shot_bit_for_bit():
         pcm = np.concatenate(list(eng.vocoder_stream([np.ascontiguousarray(mel[:, :150]), np.ascontiguousarray(mel[:, 150:])], 3, want_pcm=True)), axis=1)
         np.testing.assert_array_equal(pcm, whole_pcm)
     assert 8 <= eng.stream_halo <= 24
+    # one-shot calls between the steps of an open stream do not disturb it (its carried context lives in buffers of its own)
+    other = rng.standard_normal((2, 50, 80)).astype(np.float32)
+    pieces = []
+    for piece in eng.vocoder_stream([np.ascontiguousarray(mel[:, i:i + 37]) for i in range(0, T, 37)], 3):
+        pieces.append(piece)
+        eng.vocoder(other, 2, 50, channels_first=False)
+    np.testing.assert_array_equal(np.concatenate(pieces, axis=1), whole)
 
 
 def test_long_form_60s_stream_bf16():

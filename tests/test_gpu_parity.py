@@ -229,6 +229,41 @@ def test_steady_state_allocates_nothing_and_repeats_exactly(name):
         eng.set_ragged(True)
 
 
+def test_changing_shapes_on_one_engine_match_fresh_engines():
+    """A long-lived engine sees batches of changing size (its workspace grows, buffers are re-allocated, ragged limits change):
+    every result must be the one a fresh engine gives for that batch alone.  Also: a per-utterance speaker list equal to the
+    broadcast id gives the same bits."""
+    from e2e_tts_amd import synth_weights as sw
+    from e2e_tts_amd.runtime import engine_from_states
+    cfg = cfgmod.tiny_config()
+    ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=41, mode="varied")
+    voc = sw.make_vocoder_state(cfg, seed=42)
+    hop = cfg["audio"]["stft"]["hop_length"]
+    rng = np.random.Generator(np.random.PCG64(43))
+    shapes = [(2, 10), (5, 40), (1, 5), (3, 64), (2, 10), (7, 33), (1, 70)]   # (B, L); 64 and 70 > max_seq_len = 60
+    batches = []
+    for B, L in shapes:
+        lens = rng.integers(max(1, L // 3), L + 1, size=B).astype(np.int64)
+        lens[rng.integers(0, B)] = L
+        ids = np.zeros((B, L), np.int64)
+        for b, n in enumerate(lens):
+            ids[b, :n] = rng.integers(4, 131, size=n)
+        batches.append((ids, lens, np.array([int(rng.integers(0, 4))], np.int64)))
+    long_lived = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)
+    for ids, lens, spk in batches:
+        got, ml, T = long_lived.synthesize(ids, lens, spk)
+        fresh = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)
+        want, ml2, T2 = fresh.synthesize(ids, lens, spk)
+        assert T == T2 and (ml == ml2).all()
+        for b, n in enumerate(ml * hop):
+            np.testing.assert_array_equal(got[b, :n], want[b, :n])
+        per_utt, ml3, _ = fresh.synthesize(ids, lens, np.repeat(spk, ids.shape[0]))
+        for b, n in enumerate(ml * hop):
+            np.testing.assert_array_equal(per_utt[b, :n], want[b, :n])
+        fresh.close()
+    long_lived.close()
+
+
 def test_engines_are_thread_safe():
     """calls on one engine are serialised by its mutex, distinct engines are independent (own stream, own workspace).
     Four threads -- two sharing one engine, two on a second engine -- must each get the PCM a serial call gives (ctypes releases the

@@ -264,6 +264,76 @@ def test_changing_shapes_on_one_engine_match_fresh_engines():
     long_lived.close()
 
 
+def test_reload_and_mode_switches_leave_no_stale_state():
+    """A live engine takes new weights (fragment images, fused-pair images and bindings are rebuilt), and switching the arithmetic
+    mode / fusion / ragged compute away and back returns to the same bits.  A blob with only one of the two models refuses the
+    other half's calls."""
+    from e2e_tts_amd import packer, synth_weights as sw
+    from e2e_tts_amd._lib import Engine
+    cfg = cfgmod.tiny_config()
+    dims = cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4)
+    blobs = [packer.pack(dims, sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=51 + k, mode="varied"),
+                         sw.make_vocoder_state(cfg, seed=61 + k)) for k in range(2)]
+    rng = np.random.Generator(np.random.PCG64(53))
+    lens = np.array([21, 9, 30], np.int64)
+    ids = np.zeros((3, 30), np.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(4, 131, size=n)
+    spk = np.array([2], np.int64)
+    hop = cfg["audio"]["stft"]["hop_length"]
+
+    def run(eng):
+        pcm, ml, T = eng.synthesize(ids, lens, spk)
+        return [pcm[b, :n].copy() for b, n in enumerate(ml * hop)]
+
+    def same(a, b):
+        return len(a) == len(b) and all(x.shape == y.shape and (x == y).all() for x, y in zip(a, b))
+
+    fresh = []
+    for blob in blobs:
+        e = Engine(dims, 0)
+        e.load_weights(blob)
+        fresh.append(run(e))
+        e.close()
+    assert not same(fresh[0], fresh[1])                     # the two weight sets really differ
+    eng = Engine(dims, 0)
+    eng.load_weights(blobs[0])
+    assert same(run(eng), fresh[0])
+    eng.load_weights(blobs[1])                              # reload on a live engine
+    assert same(run(eng), fresh[1])
+    eng.load_weights(blobs[0])
+    base = run(eng)
+    assert same(base, fresh[0])
+    eng.set_precision("fp32")
+    exact = run(eng)
+    eng.set_precision("bf16x3")
+    assert same(run(eng), base)
+    assert all(np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2 for a, b in zip(exact, base))
+    eng.set_fused_resblocks(False)
+    assert same(run(eng), base)                             # fused == two-launch form, bit for bit
+    eng.set_fused_resblocks(True)
+    eng.set_ragged(False)
+    assert same(run(eng), base)
+    eng.set_ragged(True)
+    assert same(run(eng), base)
+    eng.close()
+    # half blobs
+    only_ac = Engine(dims, 0)
+    only_ac.load_weights(packer.pack(dims, sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=51, mode="varied"), None))
+    r = only_ac.acoustic(ids, lens, spk)
+    assert r["T"] > 0
+    with pytest.raises(RuntimeError):
+        only_ac.vocoder(None, 3, r["T"])
+    only_ac.close()
+    only_voc = Engine(dims, 0)
+    only_voc.load_weights(packer.pack(dims, None, sw.make_vocoder_state(cfg, seed=61)))
+    wav, _ = only_voc.vocoder(rng.standard_normal((1, 80, 12)).astype(np.float32), 1, 12)
+    assert wav.shape == (1, 12 * hop)
+    with pytest.raises(RuntimeError):
+        only_voc.acoustic(ids, lens, spk)
+    only_voc.close()
+
+
 def test_engines_are_thread_safe():
     """calls on one engine are serialised by its mutex, distinct engines are independent (own stream, own workspace).
     Four threads -- two sharing one engine, two on a second engine -- must each get the PCM a serial call gives (ctypes releases the

@@ -264,6 +264,33 @@ def test_changing_shapes_on_one_engine_match_fresh_engines():
     long_lived.close()
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 7])
+def test_vocoder_on_very_short_inputs_matches_oracle(T):
+    """Mel inputs shorter than every receptive field (T = 1: 256 samples from one frame; the dilated k = 11 convolutions reach 25
+    rows to either side): zero padding on both sides inside one tile, fused and two-launch forms, both arithmetic modes."""
+    from oracle import ref_numpy as orc
+    from e2e_tts_amd import packer, synth_weights as sw
+    from e2e_tts_amd._lib import Engine
+    cfg = cfgmod.tiny_config()
+    voc = sw.make_vocoder_state(cfg, seed=71)
+    dims = cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, 4)
+    eng = Engine(dims, 0)
+    eng.load_weights(packer.pack(dims, None, voc))
+    rng = np.random.Generator(np.random.PCG64(72 + T))
+    mel = rng.standard_normal((2, 80, T)).astype(np.float32)
+    want = orc.VocoderOracle(voc, cfg).forward(mel)[:, 0]
+    for prec in PRECISIONS:
+        eng.set_precision(prec)
+        for fused in (True, False):
+            eng.set_fused_resblocks(fused)
+            wav, pcm = eng.vocoder(mel, 2, T, pcm=True)
+            assert wav.shape == want.shape == (2, T * 256)
+            assert mean_l1(wav, want) < WAV_L1 / 10, (prec, fused)
+            ref_pcm = (want * 32768.0).astype(np.int16)
+            assert (np.abs(pcm.astype(np.int32) - ref_pcm.astype(np.int32)) <= 1).mean() >= 0.999, (prec, fused)
+    eng.close()
+
+
 def test_reload_and_mode_switches_leave_no_stale_state():
     """A live engine takes new weights (fragment images, fused-pair images and bindings are rebuilt), and switching the arithmetic
     mode / fusion / ragged compute away and back returns to the same bits.  A blob with only one of the two models refuses the

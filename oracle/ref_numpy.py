@@ -135,9 +135,12 @@ def leaky_relu(x: np.ndarray, slope: float) -> np.ndarray:
 
 
 def softmax_lastdim(x: np.ndarray) -> np.ndarray:
-    m = x.max(axis=-1, keepdims=True)
-    e = np.exp(x - m)
-    return e / e.sum(axis=-1, keepdims=True)
+    """A row of -inf only (every key masked: an utterance of zero frames) gives NaN, as torch's softmax does; the FFT block's
+    masked_fill replaces those rows afterwards (U/blocks/transformer.py:182-183)."""
+    with np.errstate(invalid="ignore"):
+        m = x.max(axis=-1, keepdims=True)
+        e = np.exp(x - m)
+        return e / e.sum(axis=-1, keepdims=True)
 
 
 def get_mask_from_lengths(lengths: np.ndarray, max_len: Optional[int] = None) -> np.ndarray:

@@ -264,6 +264,51 @@ def test_changing_shapes_on_one_engine_match_fresh_engines():
     long_lived.close()
 
 
+def test_utterance_with_zero_frames_in_a_batch():
+    """d_control < 1 can scale every duration of a short utterance below one frame (U/layers.py:218-221 multiplies after rounding,
+    the length regulator truncates): that utterance gets mel_len 0 while the batch goes on.  The reference pads it like any other
+    row; here its attention tiles, LayerNorm rows and ragged row limits all see length 0."""
+    from oracle import ref_numpy as orc
+    from e2e_tts_amd import synth_weights as sw
+    from e2e_tts_amd.runtime import engine_from_states
+    cfg = cfgmod.tiny_config()
+    ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=81, mode="varied")
+    voc = sw.make_vocoder_state(cfg, seed=82)
+    oracle = orc.AcousticOracle(ac, cfg, cfgmod.DEFAULT_STATS)
+    d_control = 0.3
+    spk = np.array([1], np.int64)
+    found = None
+    for seed in range(200):   # a 2-phoneme utterance whose durations both fall to 0 frames, next to a normal one
+        rng = np.random.Generator(np.random.PCG64(1000 + seed))
+        lens = np.array([18, 2], np.int64)
+        ids = np.zeros((2, 18), np.int64)
+        for b, n in enumerate(lens):
+            ids[b, :n] = rng.integers(4, 131, size=n)
+        (mel, mel_post, dur), ml = oracle.inference(spk, ids, lens, d_control, 1.0, 1.0)
+        d = np.exp(oracle.trace["log_d"].astype(np.float64)) - 1
+        margin = np.abs((d - np.floor(d)) - 0.5)[np.arange(18)[None, :] < lens[:, None]].min()
+        if ml[1] == 0 and ml[0] > 0 and margin > 1e-3:
+            found = (ids, lens, mel_post, dur, ml)
+            break
+    assert found is not None, "no seed gives a zero-frame utterance"
+    ids, lens, mel_post, dur, ml = found
+    eng = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)
+    for ragged in (True, False):
+        eng.set_ragged(ragged)
+        r = eng.acoustic(ids, lens, spk, d_control, 1.0, 1.0)
+        np.testing.assert_array_equal(r["dur"], dur)
+        np.testing.assert_array_equal(r["mel_lens"], ml)
+        _, mp = eng.fetch_mel(2, r["T"])
+        assert np.isfinite(mp).all() and mean_l1(mp, mel_post) < MEL_L1 / 10
+        pcm, ml2, T = eng.synthesize(ids, lens, spk, d_control, 1.0, 1.0)
+        assert (ml2 == ml).all() and T == ml[0]
+        want = orc.VocoderOracle(voc, cfg).forward(mel_post.transpose(0, 2, 1))[:, 0]
+        n = int(ml[0]) * 256
+        ref_pcm = (want[0, :n] * 32768.0).astype(np.int16)
+        assert (np.abs(pcm[0, :n].astype(np.int32) - ref_pcm.astype(np.int32)) <= 1).mean() >= 0.999
+    eng.close()
+
+
 @pytest.mark.parametrize("T", [1, 2, 3, 7])
 def test_vocoder_on_very_short_inputs_matches_oracle(T):
     """Mel inputs shorter than every receptive field (T = 1: 256 samples from one frame; the dilated k = 11 convolutions reach 25

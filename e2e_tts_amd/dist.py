@@ -52,3 +52,37 @@ def gather_pcm(local: List[Tuple[int, np.ndarray]], dst: int = 0):
     merged = [item for part in bucket for item in part]
     merged.sort(key=lambda kv: kv[0])
     return merged
+
+
+def synthesize_sharded(engine, id_lists: Sequence[Sequence[int]], speaker: int = 0, batch_size: int = 32, hop_length: Optional[int] = None,
+                       controls: Tuple[float, float, float] = (1.0, 1.0, 1.0), dst: int = 0):
+    """BASELINE config 3 end to end (256 utterances over 8 GPUs): every rank holds the SAME list of phoneme-id lists, takes its shard
+    (`shard_utterances`), synthesises it in padded batches of `batch_size` (longest first, as `TTS.input_parse` sorts,
+    reference API/utils.py:84) with its own engine, and rank `dst` receives the int16 PCM of every utterance in input order
+    (None elsewhere).  No collective on the data path: the only communication is the final gather of the PCM.
+
+    `engine` is an `e2e_tts_amd._lib.Engine` (anything with `.synthesize(ids, lens, speaker, d, p, e) -> (pcm, mel_lens, T)` and
+    `.dims.hop_length`)."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    hop = hop_length if hop_length is not None else engine.dims.hop_length
+    lens_all = [len(x) for x in id_lists]
+    if any(n <= 0 for n in lens_all):
+        raise ValueError("empty utterance")
+    mine = shard_utterances(lens_all, world)[rank]          # already longest first
+    spk = np.array([int(speaker)], np.int64)
+    local: List[Tuple[int, np.ndarray]] = []
+    for start in range(0, len(mine), batch_size):
+        idx = mine[start:start + batch_size]
+        lens = np.array([lens_all[i] for i in idx], np.int64)
+        ids = np.zeros((len(idx), int(lens.max())), np.int64)
+        for b, i in enumerate(idx):
+            ids[b, :lens[b]] = np.asarray(id_lists[i], np.int64)
+        pcm, mel_lens, _ = engine.synthesize(ids, lens, spk, *controls)
+        for b, i in enumerate(idx):
+            local.append((i, np.array(pcm[b, :int(mel_lens[b]) * hop], copy=True)))
+    merged = gather_pcm(local, dst=dst)
+    if merged is None:
+        return None
+    assert [k for k, _ in merged] == list(range(len(id_lists)))
+    return [pcm for _, pcm in merged]

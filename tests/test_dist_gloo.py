@@ -68,3 +68,53 @@ def test_broadcast_and_gather_world2(tmp_path):
     np.testing.assert_array_equal(a, b)
     assert a[0] > 1_000_000
     assert (tmp_path / "gather_ok.npy").exists()
+
+
+class _StubEngine:
+    """Stands in for the HIP engine (no GPU in the CPU suite): 'synthesises' 3 frames per phoneme whose samples encode the first id
+    of the utterance, and records the batches it was given."""
+    class dims:
+        hop_length = 4
+
+    def __init__(self):
+        self.batches = []
+
+    def synthesize(self, ids, lens, speaker, d=1.0, p=1.0, e=1.0):
+        self.batches.append((ids.shape, lens.tolist()))
+        assert (np.diff(lens) <= 0).all()                    # longest first inside a batch
+        mel_lens = lens * 3
+        T = int(mel_lens.max())
+        pcm = np.zeros((ids.shape[0], T * 4), np.int16)
+        for b in range(ids.shape[0]):
+            assert (ids[b, lens[b]:] == 0).all() and (ids[b, :lens[b]] > 0).all()
+            pcm[b, :mel_lens[b] * 4] = ids[b, 0]
+        return pcm, mel_lens, T
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.Generator(np.random.PCG64(11))           # same list on every rank
+    lists = [[int(k + 1)] + rng.integers(4, 131, size=int(n) - 1).tolist() for k, n in enumerate(rng.integers(1, 60, size=23))]
+    eng = _StubEngine()
+    out = edist.synthesize_sharded(eng, lists, speaker=1, batch_size=5)
+    assert all(shape[0] <= 5 for shape, _ in eng.batches)
+    if rank == 0:
+        assert len(out) == len(lists)
+        for k, (pcm, ids) in enumerate(zip(out, lists)):
+            assert pcm.dtype == np.int16 and pcm.shape == (len(ids) * 3 * 4,) and (pcm == k + 1).all()
+        np.save(os.path.join(out_dir, "sharded_ok.npy"), np.array([len(eng.batches)]))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_synthesize_sharded_world2(tmp_path):
+    """Config 3's flow with two ranks: shard, batch, 'synthesise', gather in input order on rank 0."""
+    port = free_port()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "sharded_ok.npy").exists()

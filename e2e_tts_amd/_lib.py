@@ -47,6 +47,10 @@ def load_library() -> C.CDLL:
     lib.e2etts_destroy.argtypes = [P]
     lib.e2etts_load_weights.restype = I
     lib.e2etts_load_weights.argtypes = [P, P, SZ]
+    lib.e2etts_load_weights_bcast.restype = I
+    lib.e2etts_load_weights_bcast.argtypes = [P, P, SZ, P, I]
+    lib.e2etts_order_after.restype = I
+    lib.e2etts_order_after.argtypes = [P, P]
     lib.e2etts_acoustic.restype = I
     lib.e2etts_acoustic.argtypes = [P, P, P, I, I, P, I, F, F, F, P, P, C.POINTER(I), P, P, P, P, P]
     lib.e2etts_fetch_mel.restype = I
@@ -96,6 +100,7 @@ EXPORTED_SYMBOLS = [
     "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
     "e2etts_fetch_wav", "e2etts_vocoder_stream_begin", "e2etts_vocoder_stream_push", "e2etts_vocoder_stream_fetch",
     "e2etts_set_precision", "e2etts_set_ragged", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_filter", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
+    "e2etts_load_weights_bcast", "e2etts_order_after",
 ]
 
 
@@ -112,6 +117,27 @@ def _addr(x) -> Optional[int]:
             raise ValueError("tensor must be contiguous")
         return x.data_ptr()
     raise TypeError(f"cannot take the address of {type(x)}")
+
+
+def _is_cuda(x) -> bool:
+    return x is not None and not isinstance(x, np.ndarray) and bool(getattr(x, "is_cuda", False))
+
+
+def _expect(x, name: str, dtype: str, count: int, at_least: bool = False):
+    """The C side reads / writes `count` elements of `dtype` behind the raw address: a wrong dtype or a short buffer would be an
+    out-of-bounds access there, so it is refused here (numpy arrays and torch tensors alike)."""
+    if x is None:
+        return
+    if isinstance(x, np.ndarray):
+        dt, n = x.dtype.name, x.size
+    elif hasattr(x, "data_ptr"):
+        dt, n = str(x.dtype).replace("torch.", ""), x.numel()
+    else:
+        raise TypeError(f"{name}: expected a numpy array or torch tensor, got {type(x)}")
+    if dt != dtype:
+        raise TypeError(f"{name}: dtype {dt}, expected {dtype}")
+    if n < count or (not at_least and n != count):
+        raise ValueError(f"{name}: {n} elements, expected {'at least ' if at_least else ''}{count}")
 
 
 def _locked(fn):
@@ -168,12 +194,38 @@ class Engine:
             raise MemoryError(msg)
         raise RuntimeError(msg)
 
+    def _order(self, *xs):
+        """Stream ordering of device buffers (include/e2etts.h, "STREAM ORDERING"): torch may still have kernels queued on its current
+        stream that write an input tensor (a `.contiguous()` copy, the caller's own producer) or read a recycled allocator block handed
+        in as an output.  The engine's stream is made to wait for that stream before the C call touches the buffers."""
+        cuda = [x for x in xs if _is_cuda(x)]
+        if not cuda:
+            return
+        import torch
+        for x in cuda:
+            if x.device.index != self.device:
+                raise ValueError(f"tensor on {x.device}, engine on cuda:{self.device}")
+        st = torch.cuda.current_stream(cuda[0].device).cuda_stream
+        self._check(self.lib.e2etts_order_after(self._h, C.c_void_p(st)), "e2etts_order_after")
+
     # ---- weights
     @_locked
     def load_weights(self, blob) -> None:
         """blob: uint8 numpy array (host) or uint8 torch tensor (host / HBM, e.g. after a RCCL broadcast)."""
         n = blob.nbytes if isinstance(blob, np.ndarray) else blob.numel() * blob.element_size()
+        _expect(blob, "blob", "uint8", n)
+        self._order(blob)
         self._check(self.lib.e2etts_load_weights(self._h, _addr(blob), n), "e2etts_load_weights")
+
+    @_locked
+    def load_weights_bcast(self, blob, nbytes: int, rccl_comm: int, root: int = 0) -> None:
+        """Collective: one RCCL broadcast of the packed image from `root` into this engine's HBM, then bind (include/e2etts.h).
+        `rccl_comm` is a raw ncclComm_t (an integer address) of the RCCL copy loaded in this process; `blob` may be None off-root."""
+        if blob is not None:
+            _expect(blob, "blob", "uint8", nbytes)
+            self._order(blob)
+        self._check(self.lib.e2etts_load_weights_bcast(self._h, _addr(blob), int(nbytes), C.c_void_p(rccl_comm), int(root)),
+                    "e2etts_load_weights_bcast")
 
     # ---- acoustic model
     @_locked
@@ -182,6 +234,12 @@ class Engine:
         Returns dict with T and the requested host arrays."""
         B, L = int(ids.shape[0]), int(ids.shape[1])
         n_spk = int(speaker.shape[0])
+        _expect(ids, "ids", "int64", B * L)
+        _expect(lens, "lens", "int64", B)
+        _expect(speaker, "speaker", "int64", n_spk)
+        if n_spk not in (1, B):
+            raise ValueError(f"speaker holds {n_spk} ids, expected 1 or {B}")
+        self._order(ids, lens, speaker)
         out = {}
         bufs = dict(
             dur=np.empty((B, L), np.float32) if "dur" in want else None,
@@ -208,6 +266,9 @@ class Engine:
     def fetch_mel(self, B: int, T: int, mel=True, mel_post=True, out_mel=None, out_mel_post=None):
         m = out_mel if out_mel is not None else (np.empty((B, T, self.dims.n_mel), np.float32) if mel else None)
         mp = out_mel_post if out_mel_post is not None else (np.empty((B, T, self.dims.n_mel), np.float32) if mel_post else None)
+        _expect(m, "mel", "float32", B * T * self.dims.n_mel)
+        _expect(mp, "mel_post", "float32", B * T * self.dims.n_mel)
+        self._order(m, mp)
         self._check(self.lib.e2etts_fetch_mel(self._h, _addr(m), _addr(mp)), "e2etts_fetch_mel")
         return m, mp
 
@@ -221,6 +282,8 @@ class Engine:
     def fetch_tap_into(self, which: str, out) -> None:
         """Like fetch_tap, into a caller buffer (numpy array or torch tensor, host or HBM)."""
         n = out.size if isinstance(out, np.ndarray) else out.numel()
+        _expect(out, "out", "float32", n)
+        self._order(out)
         self._check(self.lib.e2etts_fetch_tap(self._h, which.encode(), _addr(out), n), "e2etts_fetch_tap")
 
     # ---- vocoder
@@ -230,9 +293,12 @@ class Engine:
         n = B * T * self.dims.hop_length
         w = out_wav if out_wav is not None else (np.empty((B, T * self.dims.hop_length), np.float32) if wav else None)
         p = out_pcm if out_pcm is not None else (np.empty((B, T * self.dims.hop_length), np.int16) if pcm else None)
+        _expect(mel, "mel", "float32", B * T * self.dims.n_mel)
+        _expect(w, "out_wav", "float32", n)
+        _expect(p, "out_pcm", "int16", n)
+        self._order(mel, w, p)
         fn = self.lib.e2etts_vocoder if channels_first else self.lib.e2etts_vocoder_btc
         self._check(fn(self._h, _addr(mel), B, T, _addr(w), _addr(p)), "e2etts_vocoder")
-        del n
         return w, p
 
     # ---- end to end
@@ -246,6 +312,15 @@ class Engine:
         cap = 0
         if out_pcm is not None:
             cap = out_pcm.size if isinstance(out_pcm, np.ndarray) else out_pcm.numel()
+            _expect(out_pcm, "out_pcm", "int16", cap)
+        n_spk = int(speaker.shape[0])
+        _expect(ids, "ids", "int64", B * L)
+        _expect(lens, "lens", "int64", B)
+        _expect(speaker, "speaker", "int64", n_spk)
+        _expect(mel_lens, "out_mel_lens", "int64", B)
+        if n_spk not in (1, B):
+            raise ValueError(f"speaker holds {n_spk} ids, expected 1 or {B}")
+        self._order(ids, lens, speaker, out_pcm, mel_lens)
         rc = self.lib.e2etts_synthesize(self._h, _addr(ids), _addr(lens), B, L, _addr(speaker), int(speaker.shape[0]),
                                         float(d_control), float(p_control), float(e_control), _addr(out_pcm), cap,
                                         _addr(mel_lens), C.byref(T))

@@ -34,7 +34,7 @@ from .models import HifiGan, UnsupervisedFastSpeech2, _device_index
 
 def _load_state(path: str):
     import torch
-    ckpt = torch.load(path, map_location="cpu")
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)  # tensors only: nothing in the file is executed
     return ckpt["state_dict"]
 
 
@@ -47,7 +47,7 @@ class TTS:
         self._device_index = _device_index(device)
         base = os.path.dirname(acoustic_path)
         # the three side-car files written by save_information (reference tools_for_model.py:143-152)
-        self.config = yaml.load(open(os.path.join(base, "config.yaml"), "r"), Loader=yaml.FullLoader)
+        self.config = yaml.safe_load(open(os.path.join(base, "config.yaml"), "r"))  # plain scalars / lists / dicts only
         self.speakers = json.load(open(os.path.join(base, "speakers.json"), "r"))
         self.stats = json.load(open(os.path.join(base, "stats.json"), "r"))
         if self.config["models"]["fastspeech2"]["variance"]["duration_modelling"]["learn_alignment"] is not True:
@@ -278,7 +278,10 @@ class Synthesizer:
         ``atempo`` on the file (API/utils.py:163-172).  Here, by default (``speed_mode="duration"``), the tempo goes into the
         model instead -- ``duration_control = 1 / speed`` (U/layers.py:218-221), i.e. the phonemes are simply generated shorter
         or longer on the GPU path, with no vocoded-audio artefacts; ``speed_mode="wsola"`` post-processes the file like the
-        reference does (``audio_speed_change``).  Either way the returned path is named ``<file>_<speed>.wav`` as in the reference."""
+        reference does (``audio_speed_change``).  Either way the returned path is named ``<file>_<speed>.wav`` as in the reference,
+        and -- as in the reference, which writes the file before it runs ffmpeg on it -- ``save_filepath`` itself exists too
+        (callers such as the top-level ``synthesizer.Synthesizer`` hand that path on); in duration mode it holds the same
+        tempo-adjusted audio."""
         assert len(text) > 0
         if speed_mode not in ("duration", "wsola"):
             raise ValueError("speed_mode must be 'duration' or 'wsola'")
@@ -287,10 +290,11 @@ class Synthesizer:
         in_model = speed != 1 and speed_mode == "duration"
         audio = self.model.inference(texts=[text], speaker_id=speaker_id, pitch_control=1.0, energy_control=1.0,
                                      duration_control=(1.0 / float(speed)) if in_model else 1.0, silence_distance=0.5)
+        write_wav(save_filepath, audio, sr)
         if in_model:
             file_type = save_filepath.split(".")[-1]
             save_filepath = f"{save_filepath[:-len(file_type) - 1]}_{round(speed, 2)}.{file_type}"
-        write_wav(save_filepath, audio, sr)
+            write_wav(save_filepath, audio, sr)
         if speed != 1 and not in_model:
             save_filepath = audio_speed_change(save_filepath, speed_rate=speed)
         return save_filepath

@@ -24,6 +24,7 @@
 // bias / residual / accumulate reads and the result store are float4, 256 B contiguous per 16 lanes.
 #include <cstdlib>
 
+#include "host_logic.h"
 #include "kernels.h"
 
 namespace e2etts {
@@ -606,15 +607,11 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
 // CUs idle -> 64 x 64.  half: on the fragment path, a 128 x 128 grid whose last round of workgroups (2 per CU = 512 at a time) is
 // mostly empty -- 576 tiles for a 24576 x 384 Linear are one full round and an eighth of a second -- runs as 64 x 128 tiles: twice
 // the workgroups at half the work, e.g. 3 half-rounds instead of 2 full ones.  Same per-wave MFMA : fragment ratio (MT = 2).
-bool few_rows(const ConvParams& p) {
-  return p.Cout > 64 && (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B < 2 * 256;
-}
+bool few_rows(const ConvParams& p) { return tile_few_rows(p.B, p.T, p.Cout); }  // host_logic.h
 bool half_rows(const ConvParams& p) {
   static const bool on = !(getenv("E2ETTS_HALF_ROWS") && atoi(getenv("E2ETTS_HALF_ROWS")) == 0);  // tuning aid
-  if (!on || !p.x3 || !p.wfrag || p.accumulate || p.Cout <= 64 || few_rows(p)) return false;
-  const long long wg = (long long)((p.T + 127) / 128) * ((p.Cout + 127) / 128) * p.B, slots = 2 * 256;
-  const long long r128 = (wg + slots - 1) / slots, r64 = (2 * wg + slots - 1) / slots;
-  return 0.5 * 1.06 * (double)r64 < (double)r128;
+  if (!on || !p.x3 || !p.wfrag || p.accumulate) return false;
+  return tile_half_rows(p.B, p.T, p.Cout);
 }
 
 bool epilogue_vec_ok(const ConvParams& p) {

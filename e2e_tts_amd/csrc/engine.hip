@@ -14,7 +14,10 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/e2etts.h"
+#include "host_logic.h"
 #include "kernels.h"
 
 using namespace e2etts;
@@ -26,19 +29,6 @@ thread_local std::string g_create_error;
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
-};
-
-struct BlobHeader {
-  char magic[8];
-  uint32_t version;
-  uint32_t n_entries;
-  uint64_t data_offset;
-  uint64_t total_bytes;
-};
-struct BlobEntry {
-  char name[64];
-  uint64_t offset;
-  uint64_t numel;
 };
 
 struct FFTLayer {
@@ -538,24 +528,6 @@ int bind_vocoder(e2etts_engine* e) {
     RET(get_tensor(e, "voc.post.b", 1, &e->voc_post.b));
   }
   return E2ETTS_OK;
-}
-
-// Frames of mel context one output frame depends on, each side (conservative bound from the layer geometry: conv_post 3
-// samples, per stage the widest ResBlock1 sum_m ((k-1)/2 d_m + (k-1)/2), each upsampler +-2 input positions, conv_pre 3 frames).
-int vocoder_halo_frames(const e2etts_config& c) {
-  // HiFi-GAN tail: conv_post reaches 3 samples.  iSTFTNet tail: conv_post 3 frames + the reflection pad's shift of 1 + the inverse
-  // STFT's overlap (a sample is the sum of n_fft / hop frames: n_fft / (2 hop) to either side), all at the trunk's output rate
-  double r = c.voc_istft_nfft ? 4.0 + (double)c.voc_istft_nfft / (2.0 * c.voc_istft_hop) : 3.0;
-  for (int i = c.voc_stages - 1; i >= 0; --i) {
-    int worst = 0;
-    for (int j = 0; j < c.voc_n_kernels; ++j) {
-      int sum = 0;
-      for (int m = 0; m < c.voc_n_dil; ++m) sum += (c.voc_rb_kernel[j] - 1) / 2 * (c.voc_rb_dil[j][m] + 1);
-      worst = std::max(worst, sum);
-    }
-    r = (r + worst) / c.voc_up_rate[i] + 2.0;
-  }
-  return (int)std::ceil(r + 3.0);
 }
 
 // 6 x FFTBlock (reference U/blocks/transformer.py:178-189), in place on x ([B, N, H]); lens32: device [B]
@@ -1087,7 +1059,12 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
 
 extern "C" {
 
-const char* e2etts_version(void) { return "e2etts-hip 0.2 (gfx950; fp32 MFMA + bf16x3 split-precision MFMA)"; }
+// E2ETTS_SRC_HASH: sha256 (first 16 hex digits) of csrc/* + include/e2etts.h, passed by __graft_entry__.build(); the marker string
+// "E2ETTS_SRC_HASH=" lets build() read it from the file without loading the library, so a stale shipped .so is rebuilt, not reused.
+#ifndef E2ETTS_SRC_HASH
+#define E2ETTS_SRC_HASH "unknown"
+#endif
+const char* e2etts_version(void) { return "e2etts-hip 0.3 (gfx950; fp32 MFMA + bf16x3 split-precision MFMA) E2ETTS_SRC_HASH=" E2ETTS_SRC_HASH; }
 
 const char* e2etts_last_error(const e2etts_engine* engine) { return engine ? engine->err.c_str() : g_create_error.c_str(); }
 
@@ -1096,29 +1073,7 @@ int e2etts_create(int device_id, const e2etts_config* cfg, e2etts_engine** out) 
   *out = nullptr;
   const e2etts_config& c = *cfg;
   auto bad = [&](const char* m) { g_create_error = m; return E2ETTS_EINVAL; };
-  if (c.hidden <= 0 || c.hidden % 4 || c.n_head <= 0 || c.hidden % c.n_head) return bad("hidden must be a positive multiple of 4 and of n_head");
-  if (c.n_mel <= 0 || c.n_mel % 4) return bad("n_mel must be a positive multiple of 4");
-  if (c.ffn_dim % 4 || c.dur_chans % 4 || c.var_chans % 4 || c.postnet_dim % 4) return bad("channel counts must be multiples of 4");
-  if (c.ffn_k2 != 1 || !(c.ffn_k1 & 1)) return bad("FFN kernels must be (odd, 1)");
-  if (c.voc_stages <= 0 || c.voc_stages > E2ETTS_MAX_STAGES || c.voc_n_kernels <= 0 || c.voc_n_kernels > E2ETTS_MAX_RB_KERNELS ||
-      c.voc_n_dil <= 0 || c.voc_n_dil > E2ETTS_MAX_DILATIONS) return bad("vocoder stage / kernel / dilation counts out of range");
-  for (int i = 0; i < c.voc_stages; ++i)
-    if (c.voc_up_kernel[i] != 2 * c.voc_up_rate[i] || (c.voc_up_rate[i] & 1)) return bad("upsample kernel must be 2 x rate, rate even");
-  if ((c.voc_init_ch >> c.voc_stages) < 4 || (c.voc_init_ch % (4 << c.voc_stages))) return bad("upsample_initial_channel too small for the stage count");
-  if (c.voc_resblock != 1 && c.voc_resblock != 2) return bad("voc_resblock must be 1 or 2");
-  if (c.voc_resblock == 2 && c.voc_n_dil != 2) return bad("ResBlock2 has exactly two dilated convolutions (voc_n_dil == 2)");
-  if (c.voc_istft_nfft != 0) {
-    const int n = c.voc_istft_nfft;
-    if (n < 4 || n > 256 || (n & (n - 1)) || c.voc_istft_hop <= 0 || n % c.voc_istft_hop) return bad("iSTFT: n_fft must be a power of two in [4, 256] and a multiple of the hop");
-  }
-  if (c.block_type != 0 && c.block_type != 1) return bad("block_type must be 0 (FFT block) or 1 (Conformer block)");
-  if (c.block_type == 1) {
-    const int dh = c.hidden / c.n_head;
-    if (dh != 8 && dh != 16 && dh != 32 && dh != 48 && dh != 64 && dh != 96) return bad("Conformer head dim must be one of 8, 16, 32, 48, 64, 96");
-    if (c.ffn_dim < 2 * c.hidden) return bad("Conformer ffn_expansion_factor must be at least 2");
-  }
-  if (c.n_bins != 256) return bad("n_bins must be 256");
-  if (c.pos_table_rows < c.max_seq_len + 1) return bad("pos_table_rows must cover max_seq_len + 1");
+  if (const char* m = config_check(c)) return bad(m);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_create_error = "no HIP device visible: the e2etts engine has no CPU fallback";
@@ -1153,31 +1108,22 @@ void e2etts_destroy(e2etts_engine* e) {
   delete e;
 }
 
-int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
-  if (!e) return E2ETTS_EINVAL;
-  std::lock_guard<std::mutex> lk(e->mu);
-  HIPCHK(e, hipSetDevice(e->device));
-  if (!blob || nbytes < sizeof(BlobHeader)) return e->fail(E2ETTS_EINVAL, "weight blob too small");
+// Binds the blob resident in e->blob (nbytes bytes, copy possibly still in flight on the engine's stream): header and directory are
+// read back from HBM, validated by host_logic.h, and the tensors located.
+static int bind_resident_blob(e2etts_engine* e, size_t nbytes) {
   BlobHeader h;
-  HIPCHK(e, hipMemcpy(&h, blob, sizeof h, hipMemcpyDefault));
-  if (memcmp(h.magic, "E2ETTSW1", 8) || h.version != 1) return e->fail(E2ETTS_EINVAL, "not an e2etts weight blob (bad magic / version)");
-  if (h.total_bytes != nbytes) return e->fail(E2ETTS_EINVAL, "blob size %zu != header total %llu", nbytes, (unsigned long long)h.total_bytes);
-  const size_t dir_bytes = (size_t)h.n_entries * sizeof(BlobEntry);
-  if (h.n_entries > 100000 || sizeof h + dir_bytes > h.data_offset || h.data_offset > nbytes || (h.data_offset & 255))
-    return e->fail(E2ETTS_EINVAL, "corrupt blob directory");
+  HIPCHK(e, hipMemcpyAsync(&h, e->blob.p, sizeof h, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (const char* m = blob_check_header(h, nbytes)) return e->fail(E2ETTS_EINVAL, "%s", m);
   std::vector<BlobEntry> dir(h.n_entries);
-  HIPCHK(e, hipMemcpy(dir.data(), (const char*)blob + sizeof h, dir_bytes, hipMemcpyDefault));
-  e->ac_loaded = e->voc_loaded = false;
-  RET(ensure(e, e->blob, nbytes));
-  HIPCHK(e, hipMemcpyAsync(e->blob.p, blob, nbytes, hipMemcpyDefault, e->stream));
+  if (h.n_entries)
+    HIPCHK(e, hipMemcpy(dir.data(), (const char*)e->blob.p + sizeof h, (size_t)h.n_entries * sizeof(BlobEntry), hipMemcpyDeviceToHost));
+  std::vector<BlobTensor> ts;
+  std::string bad;
+  if (const char* m = blob_check_directory(h, dir.data(), nbytes, ts, bad)) return e->fail(E2ETTS_EINVAL, "tensor '%s': %s", bad.c_str(), m);
   e->tensors.clear();
   free_frags(e);
-  for (auto& en : dir) {
-    en.name[sizeof en.name - 1] = 0;
-    if ((en.offset & 255) || en.offset < h.data_offset || en.offset + en.numel * 4 > nbytes)
-      return e->fail(E2ETTS_EINVAL, "tensor '%s' lies outside the blob", en.name);
-    e->tensors[en.name] = {reinterpret_cast<const float*>((const char*)e->blob.p + en.offset), en.numel};
-  }
+  for (const BlobTensor& t : ts) e->tensors[t.name] = {reinterpret_cast<const float*>((const char*)e->blob.p + t.offset), t.numel};
   // a blob may carry the acoustic model, the vocoder, or both (the reference loads them from two checkpoints)
   const bool has_ac = e->tensors.count("enc.emb") != 0, has_voc = e->tensors.count("voc.pre.w") != 0;
   if (!has_ac && !has_voc) return e->fail(E2ETTS_EKEY, "blob holds neither acoustic ('enc.emb') nor vocoder ('voc.pre.w') tensors");
@@ -1186,6 +1132,87 @@ int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->ac_loaded = has_ac;
   e->voc_loaded = has_voc;
+  return E2ETTS_OK;
+}
+
+int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!blob || nbytes < sizeof(BlobHeader)) return e->fail(E2ETTS_EINVAL, "weight blob too small");
+  BlobHeader h;
+  HIPCHK(e, hipMemcpy(&h, blob, sizeof h, hipMemcpyDefault));
+  if (const char* m = blob_check_header(h, nbytes)) return e->fail(E2ETTS_EINVAL, "%s", m);  // before anything resident is touched
+  e->ac_loaded = e->voc_loaded = false;
+  RET(ensure(e, e->blob, nbytes));
+  HIPCHK(e, hipMemcpyAsync(e->blob.p, blob, nbytes, hipMemcpyDefault, e->stream));
+  return bind_resident_blob(e, nbytes);
+}
+
+// RCCL entry points, resolved at the first call: from the process image when the host already links or has loaded RCCL (the
+// communicator handed in must come from THAT copy), else from librccl.so.1 (or the file named by E2ETTS_RCCL_LIB).
+namespace {
+typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int, void* /*ncclComm_t*/, hipStream_t);
+typedef int (*nccl_rank_fn)(void*, int*);
+typedef const char* (*nccl_errstr_fn)(int);
+struct RcclApi {
+  nccl_bcast_fn bcast = nullptr;
+  nccl_rank_fn user_rank = nullptr;
+  nccl_errstr_fn errstr = nullptr;
+  std::string err;
+};
+RcclApi& rccl_api() {
+  static RcclApi api = [] {
+    RcclApi a;
+    void* h = RTLD_DEFAULT;
+    if (!dlsym(h, "ncclBroadcast")) {
+      const char* path = getenv("E2ETTS_RCCL_LIB");
+      h = dlopen(path ? path : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) {
+        const char* why = dlerror();
+        a.err = std::string("RCCL not loadable: ") + (why ? why : "?");
+        return a;
+      }
+    }
+    a.bcast = (nccl_bcast_fn)dlsym(h, "ncclBroadcast");
+    a.user_rank = (nccl_rank_fn)dlsym(h, "ncclCommUserRank");
+    a.errstr = (nccl_errstr_fn)dlsym(h, "ncclGetErrorString");
+    if (!a.bcast || !a.user_rank) a.err = "RCCL library lacks ncclBroadcast / ncclCommUserRank";
+    return a;
+  }();
+  return api;
+}
+}  // namespace
+
+int e2etts_load_weights_bcast(e2etts_engine* e, const void* blob_or_null, size_t nbytes, void* rccl_comm, int root) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!rccl_comm) return e->fail(E2ETTS_EINVAL, "rccl_comm must not be NULL");
+  if (nbytes < sizeof(BlobHeader)) return e->fail(E2ETTS_EINVAL, "weight blob too small");
+  RcclApi& api = rccl_api();
+  if (!api.err.empty()) return e->fail(E2ETTS_ESTATE, "%s", api.err.c_str());
+  int rank = -1;
+  int rc = api.user_rank(rccl_comm, &rank);
+  if (rc != 0) return e->fail(E2ETTS_EHIP, "ncclCommUserRank: %s", api.errstr ? api.errstr(rc) : "error");
+  if (rank == root && !blob_or_null) return e->fail(E2ETTS_EINVAL, "the root rank must supply the blob");
+  e->ac_loaded = e->voc_loaded = false;
+  RET(ensure(e, e->blob, nbytes));
+  if (rank == root) HIPCHK(e, hipMemcpyAsync(e->blob.p, blob_or_null, nbytes, hipMemcpyDefault, e->stream));
+  rc = api.bcast(e->blob.p, e->blob.p, nbytes, 1 /* ncclUint8 */, root, rccl_comm, e->stream);  // in place, on the engine's stream
+  if (rc != 0) return e->fail(E2ETTS_EHIP, "ncclBroadcast: %s", api.errstr ? api.errstr(rc) : "error");
+  return bind_resident_blob(e, nbytes);
+}
+
+int e2etts_order_after(e2etts_engine* e, void* caller_stream) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  hipEvent_t ev = get_event(e);
+  if (!ev) return e->fail(E2ETTS_EHIP, "hipEventCreate failed");
+  HIPCHK(e, hipEventRecord(ev, (hipStream_t)caller_stream));
+  HIPCHK(e, hipStreamWaitEvent(e->stream, ev, 0));  // the wait refers to the record above even if the event is re-recorded later
+  e->ev_pool.push_back(ev);
   return E2ETTS_OK;
 }
 

@@ -168,7 +168,9 @@ __global__ __launch_bounds__(64) void duration_kernel(const float* __restrict__ 
                                                       int32_t* __restrict__ cum, int64_t* __restrict__ mel64,
                                                       int32_t* __restrict__ mel32, int L) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  int carry = 0;
+  // Repeat counts are capped at 2^20 frames per phoneme (inf / huge exp(log_d) would overflow the int cast) and the running sum is kept
+  // in 64 bits, so a runaway prediction reaches the host as a huge mel_lens value that its T check rejects instead of a wrapped one.
+  long long carry = 0;
   for (int l0 = 0; l0 < L; l0 += 64) {
     const int l = l0 + lane;
     float d = 0.f;
@@ -177,18 +179,18 @@ __global__ __launch_bounds__(64) void duration_kernel(const float* __restrict__ 
       d = fmaxf(__fmul_rn(rintf(e), d_control), 0.f);
       dur[b * L + l] = d;
     }
-    int v = (int)d;
+    int v = d == d ? (int)fminf(d, 1048576.f) : 0;  // <= 2^20 each, 64 lanes: the wave's scan stays below 2^26
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int u = __shfl_up(v, o);
       if (lane >= o) v += u;
     }
-    if (l < L) cum[b * L + l] = carry + v;
+    if (l < L) cum[b * L + l] = (int32_t)min(carry + v, 0x7fffffffLL);
     carry += __shfl(v, 63);
   }
   if (lane == 0) {
     mel64[b] = carry;
-    mel32[b] = carry;
+    mel32[b] = (int32_t)min(carry, 0x7fffffffLL);
   }
 }
 

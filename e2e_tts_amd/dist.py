@@ -56,7 +56,7 @@ def gather_pcm(local: List[Tuple[int, np.ndarray]], dst: int = 0):
 
 def synthesize_sharded(engine, id_lists: Sequence[Sequence[int]], speaker: int = 0, batch_size: int = 32, hop_length: Optional[int] = None,
                        controls: Tuple[float, float, float] = (1.0, 1.0, 1.0), dst: int = 0):
-    """BASELINE config 3 end to end (256 utterances over 8 GPUs): every rank holds the SAME list of phoneme-id lists, takes its shard
+    """BASELINE config 4 end to end (256 utterances over 8 GPUs): every rank holds the SAME list of phoneme-id lists, takes its shard
     (`shard_utterances`), synthesises it in padded batches of `batch_size` (longest first, as `TTS.input_parse` sorts,
     reference API/utils.py:84) with its own engine, and rank `dst` receives the int16 PCM of every utterance in input order
     (None elsewhere).  No collective on the data path: the only communication is the final gather of the PCM.

@@ -64,7 +64,11 @@ class Synthesizer:
             speed = float(speed)
         language = language.split()[0]  # "<code> <Name>" (synthesizer.py:43)
         tts_output_filepath = os.path.join(self.output_dir, gen_filename())
-        self.model_dict[language].tts_to_file(text, file_path=tts_output_filepath, speed=speed)
+        # the path tts_to_file reports is the one that carries the requested tempo (<file>_<speed>.wav when speed != 1); the reference
+        # ignores it (synthesizer.py:47) and so hands the un-sped file on -- a defect the drop-in does not keep
+        made = self.model_dict[language].tts_to_file(text, file_path=tts_output_filepath, speed=speed)
+        if isinstance(made, str) and os.path.exists(made):
+            tts_output_filepath = made
         vc_output_filepath = None
         if target_filepath:
             vc_output_filepath = os.path.join(self.output_dir, gen_filename())

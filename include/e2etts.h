@@ -12,6 +12,12 @@
  *    e2etts_last_error() gives the message (no exceptions cross the boundary);
  *  - data pointers may be host OR device memory: copies use hipMemcpyDefault, so a caller that keeps
  *    its buffers in HBM (bench.py, the torch-tensor mirrors) pays no PCIe transfer;
+ *  - STREAM ORDERING of device buffers: the engine works on its own non-blocking stream and every entry point
+ *    returns only after that stream has drained, so results are complete on return.  What the engine cannot
+ *    see is work the CALLER still has queued on a stream of its own that writes an input buffer (or still reads
+ *    a buffer handed in as an output): call e2etts_order_after(engine, that_stream) first -- the engine's stream
+ *    then waits for everything queued on that stream so far -- or synchronise that stream yourself.  The Python
+ *    binding does this for every torch CUDA tensor argument (torch.cuda.current_stream());
  *  - one engine = one GPU + one HIP stream; calls on one engine are serialised by an internal mutex;
  *    distinct engines are independent (one process per GPU in multi-GPU runs);
  *  - all activations are fp32, channels-last ([B, N, C]); weights come packed by
@@ -94,6 +100,15 @@ void e2etts_destroy(e2etts_engine* engine);
  * image (host or device memory; a device image is what a RCCL broadcast from rank 0 leaves behind --
  * SURVEY.md 8(e)); it is copied into engine-owned HBM. */
 int e2etts_load_weights(e2etts_engine* engine, const void* blob, size_t nbytes);
+
+/* Multi-GPU start-up (no reference line: the reference is single-device): ONE RCCL broadcast of the packed
+ * image from rank `root` of `rccl_comm` (an ncclComm_t of the RCCL copy the host process links or has loaded; every rank's
+ * engine sits on that communicator's device), issued on the engine's stream straight into engine-owned HBM, then the same
+ * binding as e2etts_load_weights.  Collective: every rank of the communicator calls it with the same nbytes; `blob_or_null`
+ * (host or device memory) is read on the root only.  RCCL is resolved at the first call (process image, else librccl.so.1 or
+ * $E2ETTS_RCCL_LIB); E2ETTS_ESTATE if it cannot be.  Hosts that drive RCCL through torch.distributed broadcast a tensor and
+ * call e2etts_load_weights on it instead (e2e_tts_amd/dist.py) -- torch does not expose its ncclComm_t. */
+int e2etts_load_weights_bcast(e2etts_engine* engine, const void* blob_or_null, size_t nbytes, void* rccl_comm, int root);
 
 /* Replaces: UnsupervisedFastSpeech2.inference (U/model.py:155-194).
  *   ids  [B, L] int64, lens [B] int64 (1 <= lens[b] <= L), speaker [n_spk_ids] int64 with
@@ -189,6 +204,10 @@ size_t e2etts_device_bytes(const e2etts_engine* engine);
 
 /* The engine's stream as a hipStream_t cast to void* (so a caller can order its own work after ours). */
 void* e2etts_stream(e2etts_engine* engine);
+/* Orders everything the engine does from now on after the work queued so far on `caller_stream` (a hipStream_t cast to
+ * void*; NULL = the legacy default stream): an event recorded there, waited for on the engine's stream.  See "STREAM
+ * ORDERING" at the top.  Costs two API calls, no host synchronisation. */
+int e2etts_order_after(e2etts_engine* engine, void* caller_stream);
 int e2etts_sync(e2etts_engine* engine);
 
 #ifdef __cplusplus

@@ -440,6 +440,82 @@ def case_g2p():
     save("g2p", **arrays)
 
 
+def case_hifigan48k(models):
+    """BASELINE config 5's generator -- upsample_rates [8, 8, 4, 2], kernels [16, 16, 8, 4] (hop 512) -- instantiated from the reference's
+    config-driven HifiGan class (V/generator.py:14-35) at widths 64 and 512, T = 90 frames of random mel.  The reference ships no
+    48 kHz yaml; the class is what pins the arithmetic of this configuration."""
+    import torch
+    print("[hifigan_48k]", flush=True)
+    torch.set_grad_enabled(False)
+    arrays = {}
+    for tag, width, B, T, wseed, mseed in (("w64", 64, 2, 90, 31, 5), ("w512", 512, 1, 90, 34, 8)):
+        config = cfgmod.default_config()
+        config["models"]["hifigan"].update(upsample_rates=[8, 8, 4, 2], upsample_kernel_sizes=[16, 16, 8, 4], upsample_initial_channel=width)
+        config["audio"]["stft"]["hop_length"] = 512
+        config["audio"]["signal"]["sampling_rate"] = 48000
+        state = sw.make_vocoder_state(config, seed=wseed)
+        v = models.HifiGan(config["models"]["hifigan"])
+        v.load_state_dict(sw.to_torch(state), strict=True)
+        v.eval()
+        mel = np.random.Generator(np.random.PCG64(mseed)).standard_normal((B, T, 80)).astype(np.float32)   # channels-last, as the engine takes it
+        wav = v(torch.from_numpy(np.ascontiguousarray(mel.transpose(0, 2, 1)))).squeeze(1).numpy()
+        assert wav.shape == (B, T * 512), wav.shape
+        arrays[f"{tag}.mel"] = mel
+        arrays[f"{tag}.wav"] = wav.copy()
+        arrays[f"{tag}.width"] = np.int64(width)
+        arrays[f"{tag}.weight_seed"] = np.int64(wseed)
+        print(f"    {tag}: wav {wav.shape} |wav| mean {np.abs(wav).mean():.3e}", flush=True)
+    save("hifigan_48k", **arrays)
+
+
+def case_bench_b32(models):
+    """The headline workload itself (bench.py): B = 32, L = 128 phonemes each, "fixed" weights 1234 / 4321 -> T = 768.  Row 0 holds the
+    ids of c2_latency (the B = 1 latency case) so that one utterance is pinned both alone and inside the batch; rows 1..31 come from a
+    seed search like c3_mixed's.  Stored with c3_mixed's digest scheme."""
+    print("[bench_b32]", flush=True)
+    c2 = np.load(os.path.join(GOLD, "c2_latency.npz"))
+    config, stats, n_spk, speaker, controls = cfgmod.default_config(), cfgmod.DEFAULT_STATS, 4, 1, (1.0, 1.0, 1.0)
+    ac_state = sw.make_acoustic_state(config, stats, n_spk, seed=1234, mode="fixed")
+    voc_state = sw.make_vocoder_state(config, seed=4321)
+    ac_or = orc.AcousticOracle(ac_state, config, stats)
+    lens = [128] * 32
+    best = None
+    for seed in range(3000, 3040):
+        ids = np.concatenate([c2["ids"], make_ids(seed, lens[1:])], axis=0)
+        mg = oracle_margin(ac_or, ids, lens, speaker, stats, controls)
+        worst = min(mg[k] for k in ("uv", "f0", "energy"))
+        if best is None or worst > best[0]:
+            best = (worst, seed, ids)
+        if worst >= 1e-4:
+            break
+    print(f"    ids seed {best[1]}: min margin {best[0]:.2e}", flush=True)
+    seed, ids = best[1], best[2]
+    m, v = build_reference(models, config, stats, n_spk, ac_state, voc_state)
+    out = run_reference(m, v, ids, lens, speaker, controls)
+    mg = margins(out, ac_state["variance_adaptor.energy_bins"], stats, controls, lens)
+    print(f"    reference margins {mg}; T={out['mel'].shape[1]} acoustic {out['t_acoustic_s']:.2f}s vocoder {out['t_vocoder_s']:.2f}s", flush=True)
+    hop = config["audio"]["stft"]["hop_length"]
+    arrays = dict(ids=ids, lens=np.asarray(lens, np.int64), speaker=np.int64(speaker), controls=np.asarray(controls, np.float64),
+                  ids_seed=np.int64(seed), weight_seeds=np.asarray((1234, 4321), np.int64), mode=np.array("fixed"),
+                  margin_dur=mg["dur"], margin_uv=mg["uv"], margin_f0=mg["f0"], margin_energy=mg["energy"],
+                  ref_t_acoustic_s=out["t_acoustic_s"], ref_t_vocoder_s=out["t_vocoder_s"])
+    for k in ("dur", "mel_lens", "pitch_idx", "energy_idx", "log_d", "pitch_pred", "energy_pred"):
+        arrays[k] = out[k]
+    sel = np.array([0, 15, 31])
+    arrays["sel"] = sel
+    arrays["mel_post_sel"] = out["mel_post"][sel][:, ::4].copy()
+    arrays["mel_frame_stride"] = np.int64(4)
+    arrays["mel_post_sum"] = np.array([out["mel_post"][b, :n].astype(np.float64).sum() for b, n in enumerate(out["mel_lens"])])
+    arrays["mel_post_abs_sum"] = np.array([np.abs(out["mel_post"][b, :n].astype(np.float64)).sum() for b, n in enumerate(out["mel_lens"])])
+    wd = wav_digest(out["wav"], out["mel_lens"] * hop)
+    arrays["wav_strided_sel"] = out["wav"][sel][:, ::64].copy()
+    arrays["wav_stride"] = np.int64(64)
+    arrays["wav_sum"], arrays["wav_abs_sum"] = wd["wav_sum"], wd["wav_abs_sum"]
+    # int16 PCM of the selected utterances as TTS.combine_audio forms it (x 32768, truncation; API/utils.py:111-117), strided
+    arrays["pcm_strided_sel"] = (out["wav"][sel][:, ::64] * np.float32(32768.0)).astype(np.int16)
+    save("bench_b32", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -456,6 +532,7 @@ def main():
         "g2p": case_g2p,
         "voc_micro_tiny": lambda: case_vocoder_micro(models),
         "istft": lambda: case_istft(models),
+        "hifigan_48k": lambda: case_hifigan48k(models),
         "tiny_b3": lambda: case_model(models, "tiny_b3", tiny, "varied", [23, 17, 9], 1, (1.0, 1.0, 1.0), 100, 2e-3, "full"),
         "tiny_long": lambda: case_model(models, "tiny_long", tiny, "varied", [70, 33], 2, (1.0, 1.0, 1.0), 200, 2e-3, "full"),
         "tiny_ctl": lambda: case_model(models, "tiny_ctl", tiny, "varied", [12, 30, 30, 5], 0, (1.3, 0.9, 1.1), 300, 2e-3, "full"),
@@ -470,6 +547,7 @@ def main():
     large = {
         "c2_latency": lambda: case_model(models, "c2_latency", full, "fixed", [128], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
         "c3_mixed": lambda: case_model(models, "c3_mixed", full, "fixed", c3_lengths(), 1, (1.0, 1.0, 1.0), 2, 1e-4, "digest", max_tries=60),
+        "bench_b32": lambda: case_bench_b32(models),   # after c2_latency: its row 0 is that fixture's utterance
     }
     if not args.skip_large:
         jobs.update(large)

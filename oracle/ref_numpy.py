@@ -47,6 +47,19 @@ def linear(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray]) -> np.ndarray:
 
 
 _C_CONV = None
+_CONV_BACKEND = None  # None: the C / OpenMP backend when built, else numpy; "numpy"; "torch": ATen's CPU kernels (fp32 only)
+
+
+def set_conv_backend(name: Optional[str]) -> None:
+    """Which implementation conv1d / conv_transpose1d use for fp32 inputs.  "torch" runs the two primitives through
+    torch.nn.functional on the CPU -- the very kernels the reference's own CPU path executes (V/generator.py:37-53 calls
+    nn.Conv1d / nn.ConvTranspose1d) -- and exists for bench.py's cpu_baseline, which reports the faster of the backends so that
+    the stand-in is not slower than the reference's own path.  Everything else of the oracle is unchanged."""
+    global _CONV_BACKEND
+    if name not in (None, "numpy", "torch", "c"):
+        raise ValueError(name)
+    _CONV_BACKEND = name
+
 
 
 def _c_conv():
@@ -78,7 +91,15 @@ def conv1d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], padding: int =
     column buffer small enough to stay in cache).
     """
     B, Cin, T = x.shape
-    lib = _c_conv() if (x.dtype == np.float32 and w.dtype == np.float32) else None
+    f32 = x.dtype == np.float32 and w.dtype == np.float32
+    if f32 and _CONV_BACKEND == "torch":
+        import torch
+        with torch.no_grad():
+            y = torch.nn.functional.conv1d(torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(np.ascontiguousarray(w)),
+                                           None if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)),
+                                           padding=padding, dilation=dilation)
+        return y.numpy()
+    lib = _c_conv() if (f32 and _CONV_BACKEND in (None, "c")) else None
     if lib:
         Cout, _, K = w.shape
         Tout = T + 2 * padding - dilation * (K - 1)
@@ -111,6 +132,13 @@ def conv_transpose1d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stri
     """torch.nn.ConvTranspose1d.  x [B, Cin, T], w [Cin, Cout, K] -> [B, Cout, (T-1)*stride - 2*padding + K]."""
     B, Cin, T = x.shape
     _, Cout, K = w.shape
+    if _CONV_BACKEND == "torch" and x.dtype == np.float32 and w.dtype == np.float32:
+        import torch
+        with torch.no_grad():
+            y = torch.nn.functional.conv_transpose1d(torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(np.ascontiguousarray(w)),
+                                                     None if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)),
+                                                     stride=stride, padding=padding)
+        return y.numpy()
     full = np.zeros((B, Cout, (T - 1) * stride + K), dtype=x.dtype)
     wt = np.ascontiguousarray(w.transpose(2, 1, 0))  # [K, Cout, Cin]: contiguous per tap, or matmul leaves BLAS
     xc = np.ascontiguousarray(x)

@@ -114,7 +114,33 @@ def _sharded_worker(rank, world, port, out_dir):
 
 
 def test_synthesize_sharded_world2(tmp_path):
-    """Config 3's flow with two ranks: shard, batch, 'synthesise', gather in input order on rank 0."""
+    """BASELINE config 4's flow (utterance-sharded batch) with two ranks: shard, batch, 'synthesise', gather in input order on rank 0."""
     port = free_port()
     mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "sharded_ok.npy").exists()
+
+
+def test_bench_multi_rank_branch_contract_world2():
+    """bench.py's N > 1 branch on CPU: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with E2ETTS_BENCH_STUB=1
+    (a stand-in engine that computes nothing) under gloo -- rendezvous from the env, weight broadcast from rank 0, barrier-bracketed
+    timed region, MAX over ranks, exactly ONE JSON line (rank 0) carrying the driver's keys plus the multi-GPU ones."""
+    import json
+    import subprocess
+    env = dict(os.environ, E2ETTS_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["data"] == "stub"                                    # can never be mistaken for a measurement
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "utterance-sharded x2"
+    assert d["collective_backend"] == "gloo" and d["rccl_ranks"] == 0   # rccl_ranks counts ranks of an RCCL ("nccl") group only
+    assert d["weight_bcast_ms"] > 0 and d["weight_blob_bytes"] == 1 << 20
+    samples = 2 * 32 * 768 * 256                                  # whole-job aggregate: both ranks' utterances
+    assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d and "split_precision_mode" not in d   # N = 1 extras
+    for k in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "roofline", "ms_per_step_median"):
+        assert k in d, k

@@ -139,3 +139,113 @@ def test_synthesize_sharded_single_rank_matches_manual_batches():
             assert out[i].shape == (n,)
             np.testing.assert_array_equal(out[i], pcm[b, :n])
     eng.close()
+
+
+def test_inputs_written_by_pending_torch_kernels_are_ordered():
+    """include/e2etts.h "STREAM ORDERING": the engine runs on a stream of its own, so a mel that torch is STILL WRITING on its
+    current stream when v(mel) is called (the `.contiguous()` copy of `mel_post.transpose(1, 2)`, or the caller's own producer kernel)
+    must be waited for.  A long chain of torch kernels is queued in front of the kernel that fills the mel; the result has to be
+    bit-identical to the same call on a host array.  Output side: the wav lands in a block that torch's allocator has just recycled
+    from a tensor a queued kernel still reads."""
+    import torch
+    from e2e_tts_amd.models import HifiGan
+    g = load_golden("tiny_b3")
+    cfg, _, voc = states_for(g, "tiny_b3")
+    v = HifiGan(cfg["models"]["hifigan"])
+    v.load_state_dict(sw.to_torch(voc))
+    v.eval().to(torch.device("cuda", 0))
+    mel_np = np.ascontiguousarray(g["mel_post"].transpose(0, 2, 1))   # [B, 80, T]
+    want = v(mel_np).cpu().numpy()                                     # host input: nothing to order
+    dev = torch.device("cuda", 0)
+    src = torch.from_numpy(mel_np).to(dev)
+    busy = torch.randn(4096, 4096, device=dev)
+    for attempt in range(3):
+        mel = torch.full_like(src, float("nan"))
+        torch.cuda.synchronize()
+        acc = busy
+        for _ in range(40):                 # ~tens of ms of queued GEMMs on torch's current stream ...
+            acc = (acc @ busy) * 1e-3
+        mel.copy_(src + 0.0 * acc[0, 0])    # ... and only then the kernel that makes the mel valid
+        got = v(mel)                        # the binding orders the engine's stream after torch's (e2etts_order_after)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        # the reference's own call pattern: a transposed view whose .contiguous() copy is a pending torch kernel
+        mel_btc = torch.full((src.shape[0], src.shape[2], src.shape[1]), float("nan"), device=dev)
+        acc = busy
+        for _ in range(40):
+            acc = (acc @ busy) * 1e-3
+        mel_btc.copy_(src.transpose(1, 2) + 0.0 * acc[0, 0])
+        got = v(mel_btc.transpose(1, 2))
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        # output side: free a tensor that a queued kernel still reads, so that the engine's output block is that memory
+        n_out = int(np.prod(want.shape))
+        scratch = torch.ones(n_out, device=dev)
+        acc = busy
+        for _ in range(40):
+            acc = (acc @ busy) * 1e-3
+        check = (scratch * (1.0 + 0.0 * acc[0, 0])).sum()   # reads `scratch` after the GEMMs
+        del scratch                                          # the caching allocator may hand this block to torch.empty in v()
+        got = v(src)
+        assert float(check.item()) == float(n_out)           # the queued reader saw its ones, not our wav
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+_BCAST_CHILD = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from e2e_tts_amd import config as cfgmod, packer, synth_weights as sw
+from e2e_tts_amd._lib import Engine
+import torch  # the packer folds weight norm with torch ops; importing it FIRST means its bundled librccl.so (soname librccl.so.1) is the
+# one copy in this process: dlopen by that soname below -- and inside the engine -- returns the already-loaded object
+try:
+    rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+except OSError:
+    rccl = C.CDLL("/opt/rocm/lib/librccl.so.1", mode=C.RTLD_GLOBAL)
+uid = (C.c_char * 128)()
+assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+comm = C.c_void_p()
+class UID(C.Structure):
+    _fields_ = [("b", C.c_char * 128)]
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+u = UID(); C.memmove(C.byref(u), uid, 128)
+assert rccl.ncclCommInitRank(C.byref(comm), 1, u, 0) == 0, "ncclCommInitRank"
+cfg = cfgmod.tiny_config(); stats = cfgmod.DEFAULT_STATS
+dims = cfgmod.dims_from_config(cfg, stats, n_speakers=4)
+ac = sw.make_acoustic_state(cfg, stats, 4, seed=1234, mode="varied"); voc = sw.make_vocoder_state(cfg, seed=4321)
+blob = packer.pack(dims, ac, voc)
+g = np.load(sys.argv[2])
+ids, lens, spk = g["ids"], g["lens"], np.array([int(g["speaker"])], np.int64)
+a = Engine(dims, 0); a.load_weights(blob)
+b = Engine(dims, 0); b.load_weights_bcast(blob, blob.nbytes, comm.value, root=0)   # ncclBroadcast on the engine's stream
+pa, la, ta = a.synthesize(ids, lens, spk)
+pb, lb, tb = b.synthesize(ids, lens, spk)
+assert ta == tb and np.array_equal(la, lb) and np.array_equal(pa, pb)
+try:
+    b.load_weights_bcast(None, blob.nbytes, comm.value, root=0)
+    raise SystemExit("root without a blob was accepted")
+except ValueError:
+    pass
+try:
+    b.load_weights_bcast(blob, blob.nbytes, 0, root=0)
+    raise SystemExit("NULL communicator was accepted")
+except ValueError:
+    pass
+a.close(); b.close()
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+print("BCAST_OK", pa.shape, ta)
+"""
+
+
+def test_load_weights_bcast_over_rccl_single_rank_communicator(tmp_path):
+    """e2etts_load_weights_bcast: the C entry a non-Python host uses for the one RCCL collective of the path.  Run
+    in a child process that creates its own one-rank communicator through RCCL's C API (torch.distributed does not expose its
+    ncclComm_t) on this box's GPU; an engine loaded through the broadcast must synthesise the same PCM as one loaded
+    directly.  The 8-rank form is the same call on every rank."""
+    import subprocess
+    import sys
+    from conftest import GOLD, ROOT
+    script = tmp_path / "bcast_child.py"
+    script.write_text(_BCAST_CHILD)
+    r = subprocess.run([sys.executable, str(script), ROOT, os.path.join(GOLD, "tiny_b3.npz")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BCAST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1,6 +1,7 @@
 """GPU tests (-m gpu) of BASELINE config 5: 48 kHz-style HiFi-GAN (upsample 8x8x4x2 = hop 512), long-form mel stream
 (>= 60 s of audio) through the streaming vocoder in bf16.  The reference ships no 48 kHz config: its
-HifiGan class is config-driven, and so are the oracle and the engine, so the same restatement serves as the oracle."""
+HifiGan class is config-driven, and so are the oracle and the engine: fixture hifigan_48k holds that class's own output for this
+configuration (widths 64 and 512), and the >= 60 s run is then checked through size-independent properties (stream = one-shot)."""
 import numpy as np
 import pytest
 
@@ -39,12 +40,39 @@ def test_48k_vocoder_matches_oracle_in_all_precisions():
     ref = orc.VocoderOracle(voc, cfg).forward(mel.transpose(0, 2, 1))[:, 0]
     assert ref.shape == (2, 90 * 512)
     errs = {}
-    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 5e-3)):   # stated tolerance for plain bf16: 5e-3 mean-L1
+    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 1e-3)):   # plain bf16: see test_48k_vocoder_matches_reference_fixture
         eng.set_precision(prec)
         wav, _ = eng.vocoder(mel, 2, 90, channels_first=False)
         errs[prec] = mean_l1(wav, ref)
         assert errs[prec] < bar, (prec, errs[prec])
     print("48k vocoder mean-L1 vs oracle:", errs)
+    assert errs["fp32"] <= errs["bf16x3"] < errs["bf16"]
+
+
+@pytest.mark.parametrize("tag", ["w64", "w512"])
+def test_48k_vocoder_matches_reference_fixture(tag):
+    """The 48 kHz generator against the reference's own HifiGan class (fixture hifigan_48k; V/generator.py:14-53 instantiated with
+    upsample_rates [8, 8, 4, 2] / kernels [16, 16, 8, 4]) at widths 64 and 512.  fp32 and split precision meet the fp32 bar.  Plain
+    bf16 -- config 5's arithmetic -- rounds every operand to 8 significant bits (relative 2^-9 per product term); SURVEY.md 6 measured
+    torch's bf16 vocoder at wav mean-L1 1.2e-4 against fp32 on trained-scale weights, and the random-init generators here, whose
+    activations are not normalised by training, sit a few times higher: the stated bar is 1e-3 mean-L1 (|wav| mean is 5e-2..7e-2,
+    so that is <= 2 % of the signal), and the measured value is printed."""
+    from conftest import load_golden
+    g = load_golden("hifigan_48k")
+    cfg = cfg48(int(g[f"{tag}.width"]))
+    _, eng = make_engine(cfg, int(g[f"{tag}.weight_seed"]))
+    mel, ref = g[f"{tag}.mel"], g[f"{tag}.wav"]
+    B, T = mel.shape[0], mel.shape[1]
+    errs = {}
+    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 1e-3)):
+        eng.set_precision(prec)
+        wav, pcm = eng.vocoder(mel, B, T, channels_first=False, pcm=True)
+        errs[prec] = mean_l1(wav, ref)
+        assert errs[prec] < bar, (prec, errs[prec])
+        if prec != "bf16":
+            lsb = np.abs(pcm.astype(np.int32) - (ref * np.float32(32768.0)).astype(np.int16).astype(np.int32)) <= 1
+            assert lsb.mean() >= 0.999, (prec, lsb.mean())
+    print(f"48k {tag} mean-L1 vs the reference: {errs}")
     assert errs["fp32"] <= errs["bf16x3"] < errs["bf16"]
 
 
@@ -98,4 +126,4 @@ def test_long_form_60s_stream_bf16():
     exact, _ = eng.vocoder(mel, 1, T, channels_first=False)
     err = mean_l1(out, exact)
     print(f"long-form bf16 vs bf16x3: mean-L1 {err:.3e}")
-    assert err < 5e-3
+    assert err < 1e-3   # the stated plain-bf16 bar (test_48k_vocoder_matches_reference_fixture)

@@ -133,6 +133,45 @@ def test_c3_mixed_batch32():
             assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < WAV_L1 * n, prec
 
 
+def test_bench_b32_headline_workload_against_reference():
+    """The workload bench.py times (B = 32 x L = 128 phonemes, "fixed" weights 1234 / 4321 -> T = 768), pinned by the reference itself:
+    fixture bench_b32 (oracle/make_goldens.py: case_bench_b32, c3_mixed's digest scheme), in fp32 and in split precision, through
+    synthesize() -- the call bench.py makes.  Row 0 carries the ids of c2_latency: the same utterance alone (B = 1) must give the
+    same PCM bit for bit, and both must agree with what the reference produced for it at B = 32 and at B = 1."""
+    g = load_golden("bench_b32")
+    c2 = load_golden("c2_latency")
+    cfg, eng = engine_for(g, "bench_b32")
+    sel, fs, ws = g["sel"], int(g["mel_frame_stride"]), int(g["wav_stride"])
+    hop = cfg["audio"]["stft"]["hop_length"]
+    spk = np.array([int(g["speaker"])], np.int64)
+    for prec in PRECISIONS:
+        r, mel, mel_post = run_acoustic(eng, g, prec)
+        check_discrete(r, g)
+        assert r["T"] == 768
+        e_mel = mean_l1(mel_post[sel][:, ::fs], g["mel_post_sel"])
+        assert e_mel < MEL_L1, prec
+        for b, n in enumerate(g["mel_lens"]):
+            assert abs(np.abs(mel_post[b, :n].astype(np.float64)).sum() - g["mel_post_abs_sum"][b]) < MEL_L1 * n * 80, prec
+        wav, pcm_v = eng.vocoder(None, r["B"], r["T"], pcm=True)
+        e_wav = mean_l1(wav[sel][:, ::ws], g["wav_strided_sel"])
+        assert e_wav < WAV_L1, prec
+        for b, n in enumerate(g["mel_lens"] * hop):
+            assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < WAV_L1 * n, prec
+        lsb = np.abs(pcm_v[sel][:, ::ws].astype(np.int32) - g["pcm_strided_sel"].astype(np.int32)) <= 1
+        print(f"bench_b32 {prec}: mel_post mean-L1 {e_mel:.3e} wav mean-L1 {e_wav:.3e} PCM within 1 LSB {lsb.mean():.5f}")
+        assert lsb.mean() >= 0.999, prec
+        # the end-to-end call: same PCM as acoustic() + vocoder()
+        pcm, mel_lens, T = eng.synthesize(g["ids"], g["lens"], spk)
+        np.testing.assert_array_equal(mel_lens, g["mel_lens"])
+        np.testing.assert_array_equal(pcm, pcm_v)
+        # the c2_latency utterance alone: bit-identical to its row of the batch, and within the bars of the reference's B = 1 run
+        one, ml1, T1 = eng.synthesize(c2["ids"], c2["lens"], spk)
+        assert T1 == T
+        np.testing.assert_array_equal(one[0], pcm[0])
+        ref1 = (c2["wav_strided"][0] * np.float32(32768.0)).astype(np.int16)
+        assert (np.abs(one[0, ::int(c2["wav_stride"])].astype(np.int32) - ref1.astype(np.int32)) <= 1).mean() >= 0.999, prec
+
+
 def test_vocoder_stage_fixture():
     g = load_golden("voc_micro_tiny")
     from e2e_tts_amd import synth_weights as sw

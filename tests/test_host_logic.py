@@ -185,3 +185,82 @@ def test_wsola_time_stretch_and_wav_io(tmp_path):
     out = audio_speed_change(src, speed_rate=1.5)
     assert out == str(tmp_path / "a_1.5.wav") and sr2 == sr
     assert read_wav(out)[0].size == round(x.size / 1.5)
+
+
+def test_speed_paths_exist_and_facade_uses_the_returned_one(tmp_path):
+    """Synthesizer.synthesis with speed != 1 (reference API/inference.py:44-49 writes the file, THEN derives <file>_<speed>.wav from
+    it): both paths exist afterwards, the returned one carries the tempo, and the top-level facade hands the returned path on."""
+    from e2e_tts_amd import api, synthesizer as top
+
+    class StubTTS:  # stands in for the engine-backed TTS: the file handling is what is under test
+        calls = []
+
+        def inference(self, texts, speaker_id, pitch_control, energy_control, duration_control, silence_distance):
+            StubTTS.calls.append(duration_control)
+            n = int(22050 * 0.2 * duration_control)
+            return (np.arange(n) % 100).astype(np.int16)
+
+    s = api.Synthesizer.__new__(api.Synthesizer)
+    s.model, s.output_dir = StubTTS(), str(tmp_path)
+    want = str(tmp_path / "x.wav")
+    got = s.synthesis("xin chao", want, speed=1.25)
+    assert got == str(tmp_path / "x_1.25.wav") and os.path.exists(got) and os.path.exists(want)
+    assert StubTTS.calls[-1] == pytest.approx(0.8)          # tempo applied in the model: duration_control = 1 / speed
+    np.testing.assert_array_equal(api.read_wav(got)[0], api.read_wav(want)[0])
+    got = s.synthesis("xin chao", str(tmp_path / "y.wav"), speed=1.25, speed_mode="wsola")
+    assert got == str(tmp_path / "y_1.25.wav") and os.path.exists(got) and os.path.exists(str(tmp_path / "y.wav"))
+    assert api.read_wav(got)[0].size == round(api.read_wav(str(tmp_path / "y.wav"))[0].size / 1.25)
+    assert s.synthesis("xin chao", str(tmp_path / "z.wav"), speed=1) == str(tmp_path / "z.wav")
+
+    f = top.Synthesizer.__new__(top.Synthesizer)
+    f.output_dir = str(tmp_path)
+    f.model_dict = {"vie": s}
+    path, vc = f.synthesis("xin chao", "vie Vietnamese", speed=1.5)
+    assert vc is None and path.endswith("_1.5.wav") and os.path.exists(path)
+    path, _ = f.synthesis("xin chao", "vie Vietnamese", speed=1.0)
+    assert os.path.exists(path) and not path.endswith("_1.0.wav")
+
+
+def test_binding_refuses_wrong_dtypes_and_short_buffers():
+    """_lib hands raw addresses to C, which reads B * L * 8 bytes of ids etc.: dtype / element-count mismatches are refused in the
+    binding (no GPU needed: the checks run before any C call)."""
+    import torch
+    from e2e_tts_amd import _lib
+    ok = np.zeros((2, 5), np.int64)
+    _lib._expect(ok, "ids", "int64", 10)
+    _lib._expect(torch.zeros(2, 5, dtype=torch.int64), "ids", "int64", 10)
+    _lib._expect(None, "ids", "int64", 10)
+    with pytest.raises(TypeError, match="dtype int32"):
+        _lib._expect(ok.astype(np.int32), "ids", "int64", 10)
+    with pytest.raises(TypeError, match="dtype float64"):
+        _lib._expect(torch.zeros(3, dtype=torch.float64), "mel", "float32", 3)
+    with pytest.raises(ValueError, match="9 elements"):
+        _lib._expect(np.zeros(9, np.int64), "lens", "int64", 10)
+    with pytest.raises(ValueError, match="12 elements, expected 10"):
+        _lib._expect(np.zeros(12, np.int64), "lens", "int64", 10)
+    _lib._expect(np.zeros(12, np.int16), "out_pcm", "int16", 10, at_least=True)
+    with pytest.raises(TypeError):
+        _lib._expect([1, 2, 3], "ids", "int64", 3)
+
+    class E(_lib.Engine):  # the argument checks of the public methods, reached without constructing an engine
+        def __init__(self):
+            import threading
+            self.lock = threading.RLock()
+            self.dims = cfgmod.dims_from_config(cfgmod.tiny_config(), cfgmod.DEFAULT_STATS, 4)
+            self.device = 0
+
+        def __del__(self):
+            pass
+
+    e = E()
+    ids, lens, spk = np.zeros((2, 5), np.int64), np.full((2,), 5, np.int64), np.array([1], np.int64)
+    with pytest.raises(TypeError, match="ids: dtype int32"):
+        e.synthesize(ids.astype(np.int32), lens, spk)
+    with pytest.raises(ValueError, match="lens: 1 elements, expected 2"):
+        e.acoustic(ids, lens[:1], spk)
+    with pytest.raises(ValueError, match="speaker holds 3 ids"):
+        e.acoustic(ids, lens, np.array([1, 1, 1], np.int64))
+    with pytest.raises(TypeError, match="mel: dtype float64"):
+        e.vocoder(np.zeros((1, e.dims.n_mel, 4)), 1, 4)
+    with pytest.raises(ValueError, match="out_wav"):
+        e.vocoder(np.zeros((1, e.dims.n_mel, 4), np.float32), 1, 4, out_wav=np.zeros(7, np.float32))

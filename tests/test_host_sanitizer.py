@@ -1,0 +1,137 @@
+"""The engine's HIP-free host logic (e2e_tts_amd/csrc/host_logic.h: weight-blob header / directory validation, config
+validation, vocoder halo, conv_gemm tile choice) built with AddressSanitizer + UBSan on the CPU (the reference
+has no sanitizer target; GPU ASan is not available on this pool) and fed valid, truncated and corrupt inputs.  engine.hip and
+conv_gemm.hip include the same header, so this is the code the library ships."""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from e2e_tts_amd import config as cfgmod, packer, synth_weights as sw
+
+SRC = os.path.join(ROOT, "tests", "csrc", "host_logic_test.cc")
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("san") / "host_logic_test")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", SRC, "-o", exe]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def run(exe, *args):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, f"sanitizer report or crash (rc={r.returncode}):\n{r.stderr[-3000:]}"
+    return r.stdout.strip()
+
+
+@pytest.fixture(scope="module")
+def tiny_blob():
+    cfg = cfgmod.tiny_config()
+    dims = cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, n_speakers=4)
+    ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=1234, mode="varied")
+    voc = sw.make_vocoder_state(cfg, seed=4321)
+    return dims, packer.pack(dims, ac, voc)
+
+
+def test_valid_blob_parses(harness, tiny_blob, tmp_path):
+    _, blob = tiny_blob
+    f = tmp_path / "ok.blob"
+    blob.tofile(f)
+    out = run(harness, "blob", f)
+    n_entries = struct.unpack_from("<I", blob, 12)[0]
+    assert out.startswith(f"OK {n_entries} "), out
+
+
+def test_truncated_blobs_are_rejected_without_overreads(harness, tiny_blob, tmp_path):
+    _, blob = tiny_blob
+    data_offset = struct.unpack_from("<Q", blob, 16)[0]
+    for n in (0, 1, 31, 32, 33, 111, 112, int(data_offset) - 1, int(data_offset), int(data_offset) + 255, blob.size // 2, blob.size - 1):
+        f = tmp_path / f"trunc{n}.blob"
+        blob[:n].tofile(f)
+        assert run(harness, "blob", f).startswith("ERR"), n
+    # truncated AND the header patched to claim the shorter size: the directory entries that now point past the end must be caught
+    for n in (int(data_offset), int(data_offset) + 256, blob.size // 2 // 256 * 256):
+        b = blob[:n].copy()
+        struct.pack_into("<Q", b, 24, n)
+        f = tmp_path / f"relabel{n}.blob"
+        b.tofile(f)
+        assert run(harness, "blob", f).startswith("ERR tensor"), n
+
+
+def test_corrupt_headers_and_directories_are_rejected(harness, tiny_blob, tmp_path):
+    _, blob = tiny_blob
+    n_entries = struct.unpack_from("<I", blob, 12)[0]
+    data_offset = struct.unpack_from("<Q", blob, 16)[0]
+
+    def variant(name, patch):
+        b = blob.copy()
+        patch(b)
+        f = tmp_path / f"{name}.blob"
+        b.tofile(f)
+        return run(harness, "blob", f)
+
+    assert variant("magic", lambda b: b.__setitem__(0, 0x58)).startswith("ERR not an e2etts")
+    assert variant("version", lambda b: struct.pack_into("<I", b, 8, 2)).startswith("ERR not an e2etts")
+    assert variant("entries_huge", lambda b: struct.pack_into("<I", b, 12, 0xFFFFFFFF)).startswith("ERR corrupt blob directory")
+    assert variant("entries_past_data", lambda b: struct.pack_into("<I", b, 12, n_entries + 100000 - n_entries % 100000 - 1)).startswith("ERR")
+    assert variant("entries_plus_some", lambda b: struct.pack_into("<I", b, 12, (data_offset - 32) // 80 + 1)).startswith("ERR corrupt blob directory")
+    assert variant("data_offset_unaligned", lambda b: struct.pack_into("<Q", b, 16, data_offset + 4)).startswith("ERR corrupt blob directory")
+    assert variant("data_offset_past_end", lambda b: struct.pack_into("<Q", b, 16, (blob.size + 255) // 256 * 256 + 256)).startswith("ERR corrupt blob directory")
+    assert variant("total", lambda b: struct.pack_into("<Q", b, 24, blob.size + 1)).startswith("ERR blob size")
+    first = 32  # first directory entry: name[64], offset, numel
+    for name, off, numel in (("off_unaligned", data_offset + 4, 1), ("off_before_data", 0, 1), ("off_past_end", 1 << 40, 1),
+                             ("numel_huge", data_offset, (1 << 64) - 1), ("numel_wraps", data_offset, (1 << 62) + 7),
+                             ("numel_one_too_many", data_offset, (blob.size - data_offset) // 4 + 1)):
+        out = variant(name, lambda b: struct.pack_into("<QQ", b, first + 64, off, numel))
+        assert out.startswith("ERR tensor"), (name, out)
+    # an entry name without a terminating NUL must not be read past its 64 bytes
+    out = variant("name_unterminated", lambda b: b.__setitem__(slice(first, first + 64), 0x41))
+    assert out.startswith("OK") or out.startswith("ERR"), out
+    # the largest tensor that still fits is accepted
+    out = variant("numel_exact", lambda b: struct.pack_into("<QQ", b, first + 64, data_offset, (blob.size - data_offset) // 4))
+    assert out.startswith("OK"), out
+
+
+def test_config_validation_and_halo(harness, tiny_blob, tmp_path):
+    dims, _ = tiny_blob
+    good = dims.to_c()
+    raw = bytes(ctypes.string_at(ctypes.addressof(good), ctypes.sizeof(good)))
+    f = tmp_path / "cfg.bin"
+    f.write_bytes(raw)
+    assert run(harness, "config", f).startswith("OK halo=")
+    d = cfgmod.dims_from_config(cfgmod.default_config(), cfgmod.DEFAULT_STATS, n_speakers=4).to_c()
+    f.write_bytes(bytes(ctypes.string_at(ctypes.addressof(d), ctypes.sizeof(d))))
+    assert run(harness, "config", f) == "OK halo=15"   # HiFi-GAN V1 (include/e2etts.h: streaming vocoder)
+    # every int32 field forced to hostile values: rejected or accepted, never a sanitizer report (shift / overflow / index)
+    n_fields = len(raw) // 4
+    for val in (0, -1, 0x7FFFFFFF, -0x80000000, 1 << 20, 3):
+        for i in range(n_fields):
+            b = bytearray(raw)
+            struct.pack_into("<i", b, 4 * i, val)
+            f.write_bytes(bytes(b))
+            out = run(harness, "config", f)
+            assert out.startswith("OK") or out.startswith("ERR"), (i, val, out)
+    rng = np.random.Generator(np.random.PCG64(7))
+    for _ in range(200):
+        f.write_bytes(rng.integers(0, 256, size=len(raw), dtype=np.uint8).tobytes())
+        out = run(harness, "config", f)
+        assert out.startswith("OK") or out.startswith("ERR"), out
+
+
+def test_tile_choice(harness):
+    # the headline workload's shapes: decoder Linear 24576 x 384 -> 64 x 128 tiles; big vocoder layers stay 128 x 128;
+    # the encoder (B * L phonemes) and B = 1 take the few-rows tile
+    assert run(harness, "tiles", 32, 768, 384) == "few=0 half=1"
+    assert run(harness, "tiles", 32, 6144, 256) == "few=0 half=0"
+    assert run(harness, "tiles", 32, 128, 384) == "few=1 half=0"
+    assert run(harness, "tiles", 1, 768, 1024) == "few=1 half=0"
+    assert run(harness, "tiles", 32, 768, 64) == "few=0 half=0"
+    for args in ((0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF), (1, 1, 65), (4096, 1 << 20, 8192)):
+        assert run(harness, "tiles", *args).startswith("few=")

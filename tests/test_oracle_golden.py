@@ -141,3 +141,51 @@ def test_istft_oracle_matches_reference(tag):
     np.testing.assert_allclose(phase, g[f"{tag}.phase"], rtol=0, atol=5e-6)
     np.testing.assert_allclose(o.inverse(g[f"{tag}.spec"], g[f"{tag}.phase"]), g[f"{tag}.wav"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(o.wav(g[f"{tag}.mel"]), g[f"{tag}.wav"], rtol=0, atol=5e-6)
+
+
+def cfg48(width):
+    """BASELINE config 5's generator: the reference's config-driven HifiGan (V/generator.py:14-35) with rates 8 x 8 x 4 x 2 = hop 512."""
+    cfg = cfgmod.default_config()
+    cfg["models"]["hifigan"].update(upsample_rates=[8, 8, 4, 2], upsample_kernel_sizes=[16, 16, 8, 4], upsample_initial_channel=width)
+    cfg["audio"]["stft"]["hop_length"] = 512
+    cfg["audio"]["signal"]["sampling_rate"] = 48000
+    return cfg
+
+
+@pytest.mark.parametrize("tag", ["w64", "w512"])
+def test_48k_vocoder_oracle_matches_reference(tag):
+    """The 48 kHz generator as the reference's own HifiGan class computes it (fixture hifigan_48k, oracle/make_goldens.py:
+    case_hifigan48k), widths 64 and 512."""
+    from e2e_tts_amd import synth_weights as sw
+    g = load_golden("hifigan_48k")
+    cfg = cfg48(int(g[f"{tag}.width"]))
+    voc = orc.VocoderOracle(sw.make_vocoder_state(cfg, seed=int(g[f"{tag}.weight_seed"])), cfg)
+    wav = voc.forward(g[f"{tag}.mel"].transpose(0, 2, 1))[:, 0]
+    assert wav.shape == g[f"{tag}.wav"].shape
+    assert mean_l1(wav, g[f"{tag}.wav"]) < 1e-6
+    assert np.abs(wav - g[f"{tag}.wav"]).max() < 2e-5
+
+
+@pytest.mark.slow
+def test_bench_batch_row0_oracle_matches_reference():
+    """bench_b32 (the headline workload, B = 32 x L = 128): the oracle on row 0 alone -- fixed-length batches have no padding, so an
+    utterance's result does not depend on its batch -- against the reference's B = 32 output for that row, and against c2_latency
+    (the same ids run by the reference at B = 1)."""
+    g = load_golden("bench_b32")
+    c2 = load_golden("c2_latency")
+    np.testing.assert_array_equal(g["ids"][0], c2["ids"][0])
+    cfg, ac_state, voc_state = states_for(g, "bench_b32")
+    ac = orc.AcousticOracle(ac_state, cfg, cfgmod.DEFAULT_STATS)
+    (mel, mel_post, dur), mel_lens = ac.inference(np.array([int(g["speaker"])]), g["ids"][:1], g["lens"][:1])
+    np.testing.assert_array_equal(dur, g["dur"][:1])
+    np.testing.assert_array_equal(ac.trace["pitch_idx"], g["pitch_idx"][:1])
+    np.testing.assert_array_equal(ac.trace["energy_idx"], g["energy_idx"][:1])
+    assert int(g["sel"][0]) == 0
+    fs = int(g["mel_frame_stride"])
+    assert mean_l1(mel_post[0, ::fs], g["mel_post_sel"][0]) < 1e-5
+    assert mean_l1(mel_post, c2["mel_post"]) < 1e-5
+    wav = orc.VocoderOracle(voc_state, cfg).forward(mel_post.transpose(0, 2, 1))[:, 0]
+    s = int(g["wav_stride"])
+    assert mean_l1(wav[0, ::s], g["wav_strided_sel"][0]) < 1e-5
+    assert abs(np.abs(wav[0].astype(np.float64)).sum() - g["wav_abs_sum"][0]) < 1e-5 * wav.shape[1]
+    assert mean_l1(wav[:, ::int(c2["wav_stride"])], c2["wav_strided"]) < 1e-5

@@ -35,6 +35,10 @@ def load_library() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  e2e_tts_amd has no CPU fallback.")
+    # ONE HIP runtime per process: torch ships its own libamdhip64.so (soname libamdhip64.so.7) and resolves it by file name, so if this
+    # library -- which needs "libamdhip64.so.7" -- were loaded first it would pull in /opt/rocm's copy and a later `import torch` would
+    # bring a second runtime that finds no GPU ("No HIP GPUs are available").  With torch loaded first the soname matches its copy.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     P, I, F, SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     lib.e2etts_version.restype = C.c_char_p

@@ -102,7 +102,6 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
 //        barriers and a staging pass per 24 MFMAs of a wave; with CPI planes it is one per 24 CPI.  Same chunk order, same bits.
 template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
-  static_assert(!BFRAG || MODE != 0, "fragment-order weights exist for the bf16 modes only");
   constexpr bool K1 = CPI > 0;
   static_assert(!K1 || BFRAG, "multi-chunk items exist on the fragment path only");
   constexpr bool X3 = MODE != 0;
@@ -165,7 +164,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((long long)p.Cout * KC * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t in_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((long long)p.T * p.in_ld * 4), 0x00020000);
-  // BFRAG: weights in fragment order [n_tile32][tap][chunk][k-step][hi|lo][lane][8 bf16]: one fully coalesced 1 KiB
+  // BFRAG: weights in fragment order [n_tile32][tap][chunk][k-step][hi|lo][lane][8 bf16] (bf16 modes) or
+  // [n_tile32][tap][chunk][q 0..3][lane][4 floats] (fp32: lane (li, lh) holds k = 8 q + 4 lh .. + 3 of column li, the float4 the LDS
+  // tile would have given it) -- either way 4 KiB per (tile, tap, chunk) in 1 KiB pieces: one fully coalesced 1 KiB
   // buffer_load_dwordx4 per fragment, per wave, served by L2 (the tensor is <= a few MB and shared by every workgroup).
   // No LDS tile, no ds_write pass and -- the point -- no workgroup barrier per tap: barriers remain per slab only.
   const int ntile32 = (p.Cout + 31) / 32;
@@ -181,13 +182,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   int fnt[NT];  // this wave's 32-column tiles (clamped: columns beyond Cout are never stored)
 #pragma unroll
   for (int n = 0; n < NT; ++n) fnt[n] = min((n0 + wn * WN) / 32 + n, ntile32 - 1);
-  float4 bfr[BK / 16][NT][2];  // [k-step][n tile][hi | lo] fragments of the CURRENT iteration (BFRAG)
+  constexpr int KS = X3 ? BK / 16 : BK / 8;  // k-steps per 32-channel chunk: 2 x 16 (bf16 MFMA) or 4 x (4 MFMAs of k = 2) (fp32)
+  constexpr int HL = X3 ? 2 : 1;
+  float4 bfr[KS][NT][HL];  // [k-step][n tile][hi | lo] fragments of the CURRENT iteration (BFRAG)
   auto load_frag = [&](int chunk, int j, int ks) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int hl = 0; hl < 2; ++hl) {
-        const int soff = ((((fnt[n] * p.KW + j) * nchunk + chunk) * (BK / 16) + ks) * 2 + hl) * 1024;
+      for (int hl = 0; hl < HL; ++hl) {
+        const int soff = ((((fnt[n] * p.KW + j) * nchunk + chunk) * KS + ks) * HL + hl) * 1024;
         bfr[ks][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
       }
   };
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   store_a();
   if constexpr (BFRAG) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) load_frag(0, 0, ks);
+    for (int ks = 0; ks < KS; ++ks) load_frag(0, 0, ks);
     // hipcc may issue these in any order; whatever is still in flight at the loop head would force the head's wait for
     // the first fragment down to vmcnt(0) in EVERY iteration.  Drained here, the wait inside the loop stays counted.
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -510,11 +513,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
     } else {
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
+        if (!BFRAG || j != skip_tap) {  // wave-uniform (see the bf16 branch)
         float4 af[MT], bf[NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + q * 8);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + q * 8);
+        for (int n = 0; n < NT; ++n) {
+          if constexpr (BFRAG) bf[n] = bfr[q][n][0];
+          else bf[n] = *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + q * 8);
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -524,6 +531,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
           }
+        }
+        if constexpr (BFRAG) {  // as in the bf16 branch: this k-step's fragments for the NEXT iteration, unconditionally
+          if constexpr (K1) {
+            load_frag(last_tap ? nchk * CPI : chunk * CPI + j + 1, 0, q);
+          } else {
+            if (!last_tap) load_frag(chunk, j + 1, q);
+            else load_frag(nchk, 0, q);
+          }
+        }
       }
     }
     __builtin_amdgcn_s_setprio(3);
@@ -586,7 +602,7 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
 // at 64 and 32 columns, where the weight tile is small next to the slab.
 template <int BM, int BN, int WM, int WN, int MODE>
 const char* launch_cfg(const ConvParams& p, hipStream_t s) {
-  if constexpr (MODE != 0 && BN == 128) {
+  if constexpr (BN == 128) {
     // plain Linear layers (q | k | v, fc, the k = 1 FFN conv, every Conformer GEMM): several chunks per work item
     static const int cpi_env = getenv("E2ETTS_K1_CPI") ? atoi(getenv("E2ETTS_K1_CPI")) : 4;  // tuning aid: 0 = off, 2, 4
     if constexpr (BM == 128 || BM == 64) {
@@ -610,7 +626,7 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
 bool few_rows(const ConvParams& p) { return tile_few_rows(p.B, p.T, p.Cout); }  // host_logic.h
 bool half_rows(const ConvParams& p) {
   static const bool on = !(getenv("E2ETTS_HALF_ROWS") && atoi(getenv("E2ETTS_HALF_ROWS")) == 0);  // tuning aid
-  if (!on || !p.x3 || !p.wfrag || p.accumulate) return false;
+  if (!on || !p.wfrag || p.accumulate) return false;
   return tile_half_rows(p.B, p.T, p.Cout);
 }
 
@@ -633,7 +649,7 @@ const char* conv_gemm_class(const ConvParams& p) {
     if (half_rows(p)) return "conv_x3_64x128";
     return p.Cout > 64 ? "conv_x3_128x128" : (p.Cout > 32 ? "conv_x3_256x64" : "conv_x3_256x32");
   }
-  if (p.Cout > 64) return few_rows(p) ? "conv_gemm_64x64" : "conv_gemm_128x128";
+  if (p.Cout > 64) return few_rows(p) ? "conv_gemm_64x64" : (half_rows(p) ? "conv_gemm_64x128" : "conv_gemm_128x128");
   return p.Cout > 32 ? "conv_gemm_256x64" : "conv_gemm_256x32";
 }
 
@@ -684,6 +700,7 @@ const char* launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   if (p.Cout > 64) {
     // (the encoder and the variance adaptor see B * L phonemes, not B * T frames: always few rows)
     if (few) return launch_cfg<64, 64, 32, 32, 0>(p, s);
+    if (half) return launch_cfg<64, 128, 64, 32, 0>(p, s);
     return launch_cfg<128, 128, 64, 64, 0>(p, s);
   }
   if (p.Cout > 32) return launch_cfg<256, 64, 64, 64, 0>(p, s);

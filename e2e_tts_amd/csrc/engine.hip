@@ -258,7 +258,7 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
   if (p.in_bs == 0) p.in_bs = (long long)p.T * p.in_ld;
   if (p.out_bs == 0) p.out_bs = (long long)p.T * p.out_ld;
   if (p.res && p.res_bs == 0) p.res_bs = (long long)p.T * p.res_ld;
-  if (p.x3 && !p.wfrag) {
+  if (!p.wfrag) {  // fragment-order image of these weights (split-precision image or fp32 tensor: the map is keyed by pointer)
     auto it = e->frag_of.find(p.w);
     if (it != e->frag_of.end()) p.wfrag = it->second;
   }
@@ -299,6 +299,20 @@ int make_frag(e2etts_engine* e, const float* wx3, uint64_t cout, uint64_t kw, ui
   return E2ETTS_OK;
 }
 
+// fp32 weights of a layer the 128-column kernels serve (Cout > 64) -> fp32 fragment order, for the exact-fp32 mode
+int make_frag32(e2etts_engine* e, const float* w, uint64_t cout, uint64_t kw, uint64_t cin) {
+  static const bool off = getenv("E2ETTS_NO_FRAG32") != nullptr;  // tuning aid: A/B against the LDS weight tile
+  if (off || !w || cout <= 64 || e->frag_of.count(w)) return E2ETTS_OK;
+  float* f = nullptr;
+  const size_t bytes = x3_frag_bytes((int)cout, (int)kw, (int)cin);
+  HIPCHK(e, hipMalloc(&f, bytes));
+  e->dev_bytes += bytes;
+  e->frag_bytes += bytes;
+  e->frag_of[w] = f;
+  KCHK(e, launch_f32_to_frag(w, f, (int)cout, (int)kw, (int)cin, e->stream));
+  return E2ETTS_OK;
+}
+
 int get_tensor(e2etts_engine* e, const std::string& name, uint64_t numel, const float** out) {
   auto it = e->tensors.find(name);
   if (it == e->tensors.end()) return e->fail(E2ETTS_EKEY, "weight blob has no tensor '%s'", name.c_str());
@@ -328,6 +342,10 @@ int bind_fft(e2etts_engine* e, const char* side, int layers, std::vector<FFTLaye
     RET(get_tensor(e, p + "b2", H, &f.b2));
     RET(get_tensor(e, p + "ln2.g", H, &f.ln2g));
     RET(get_tensor(e, p + "ln2.b", H, &f.ln2b));
+    RET(make_frag32(e, f.wqkv, 3 * H, 1, H));
+    RET(make_frag32(e, f.wo, H, 1, H));
+    RET(make_frag32(e, f.w1, F, c.ffn_k1, H));
+    RET(make_frag32(e, f.w2, H, 1, F));
     const uint64_t Hc = (H + 31) / 32 * 32, Fc = (F + 31) / 32 * 32;
     if (e->tensors.count(p + "wqkv.x3")) {
       RET(get_tensor(e, p + "wqkv.x3", 3 * H * Hc, &f.wqkv_x3));
@@ -345,6 +363,7 @@ int bind_fft(e2etts_engine* e, const char* side, int layers, std::vector<FFTLaye
 
 int bind_cf_gemm(e2etts_engine* e, const std::string& name, const char* bias, uint64_t cout, uint64_t cin, CfGemm& g) {
   RET(get_tensor(e, name, cout * cin, &g.w));
+  RET(make_frag32(e, g.w, cout, 1, cin));
   g.b = nullptr;
   if (bias) RET(get_tensor(e, bias, cout, &g.b));
   g.wx3 = nullptr;
@@ -403,6 +422,7 @@ int bind_pred(e2etts_engine* e, const char* name, int layers, int kernel, int ch
     std::string p = std::string(name) + "." + std::to_string(i) + ".";
     const uint64_t cin = i == 0 ? H : (uint64_t)chans;
     RET(get_tensor(e, p + "w", (uint64_t)chans * kernel * cin, &pr.layers[i].w));
+    RET(make_frag32(e, pr.layers[i].w, chans, kernel, cin));
     RET(get_tensor(e, p + "b", chans, &pr.layers[i].b));
     RET(get_tensor(e, p + "g", chans, &pr.layers[i].g));
     RET(get_tensor(e, p + "beta", chans, &pr.layers[i].beta));
@@ -442,6 +462,7 @@ int bind_acoustic(e2etts_engine* e) {
   RET(get_tensor(e, "energy.emb", (uint64_t)c.n_bins * H, &e->energy_emb));
   RET(get_tensor(e, "energy.bins", (uint64_t)c.n_bins - 1, &e->energy_bins));
   RET(get_tensor(e, "mel.w", (uint64_t)c.n_mel * H, &e->mel_lin.w));
+  RET(make_frag32(e, e->mel_lin.w, c.n_mel, 1, H));
   RET(get_tensor(e, "mel.b", c.n_mel, &e->mel_lin.b));
   e->mel_lin.wx3 = nullptr;
   if (e->tensors.count("mel.w.x3")) RET(get_tensor(e, "mel.w.x3", (uint64_t)c.n_mel * ((H + 31) / 32 * 32), &e->mel_lin.wx3));
@@ -451,6 +472,7 @@ int bind_acoustic(e2etts_engine* e) {
     const uint64_t cin = i == 0 ? c.n_mel : c.postnet_dim, cout = i == c.postnet_layers - 1 ? c.n_mel : c.postnet_dim;
     std::string p = "post." + std::to_string(i) + ".";
     RET(get_tensor(e, p + "w", cout * c.postnet_kernel * cin, &e->postnet[i].w));
+    RET(make_frag32(e, e->postnet[i].w, cout, c.postnet_kernel, cin));
     RET(get_tensor(e, p + "b", cout, &e->postnet[i].b));
     e->postnet[i].wx3 = nullptr;
     if (e->tensors.count(p + "w.x3")) RET(get_tensor(e, p + "w.x3", cout * c.postnet_kernel * ((cin + 31) / 32 * 32), &e->postnet[i].wx3));
@@ -462,6 +484,7 @@ int bind_acoustic(e2etts_engine* e) {
 // fp32 weight + bias (required) and the split-precision image (optional: older blobs do not carry it)
 int bind_conv(e2etts_engine* e, const std::string& name, uint64_t cout, uint64_t kw, uint64_t cin, ConvW& w) {
   RET(get_tensor(e, name + ".w", cout * kw * cin, &w.w));
+  RET(make_frag32(e, w.w, cout, kw, cin));
   RET(get_tensor(e, name + ".b", cout, &w.b));
   w.wx3 = nullptr;
   if (e->tensors.count(name + ".wx3")) RET(get_tensor(e, name + ".wx3", cout * kw * ((cin + 31) / 32) * 32, &w.wx3));

@@ -17,8 +17,9 @@ struct ConvParams {
   const float* w = nullptr;      // [Cout, KW*Cin] tap-major fp32; x3: [Cout, KW, ceil(Cin/32), 32 bf16 hi | 32 bf16 lo]
   int zero_tap_split = 0;        // polyphase upsampler (KW == 3): columns < split have an all-zero tap 2, columns >= split an all-zero
                                  // tap 0 (packer.polyphase_upsampler); the fragment path skips those MFMAs.  0: no structural zeros
-  const float* wfrag = nullptr;  // x3 only, optional: the same weights in MFMA-fragment order (launch_x3_to_frag); when set,
-                                 // each wave loads its B fragments straight from global / L2 and the weight tile skips LDS
+  const float* wfrag = nullptr;  // optional: the same weights in MFMA-fragment order (launch_x3_to_frag for the bf16 modes,
+                                 // launch_f32_to_frag for fp32); when set, each wave of the 128-column kernels loads its B
+                                 // fragments straight from global / L2 and the weight tile skips LDS
   int x3 = 0;                    // 1: split-precision bf16x3 MFMA path (w pre-split by the packer); 2: plain bf16 (hi x hi only)
   const float* bias = nullptr;   // [Cout] or null
   const float* res = nullptr;    // optional residual, same indexing as out
@@ -102,6 +103,8 @@ double resblock_pair_bytes(const PairParams& p);
 // split-precision weight image -> MFMA-fragment order (ConvParams::wfrag)
 const char* launch_x3_to_frag(const float* x3, float* frag, int Cout, int KW, int Cin, hipStream_t s);
 size_t x3_frag_bytes(int Cout, int KW, int Cin);
+// fp32 weights [Cout][KW * Cin] -> the fp32 fragment order (same size as the bf16 one: 4 KiB per (32 columns, tap, 32 channels))
+const char* launch_f32_to_frag(const float* w, float* frag, int Cout, int KW, int Cin, hipStream_t s);
 
 // iSTFTNet tail: leaky ReLU + ReflectionPad1d((1, 0)) on channels-last frames; exp / sin heads, inverse STFT with overlap-add
 const char* launch_reflect_lrelu(const float* in, float* out, int B, long long n, int C, float slope, hipStream_t s);

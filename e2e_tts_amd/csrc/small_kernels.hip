@@ -294,6 +294,30 @@ __global__ void x3_to_frag_kernel(const uint4* __restrict__ x3, uint4* __restric
   frag[g] = v;
 }
 
+// fp32 weights [Cout][KW * Cin] (tap-major) -> MFMA-fragment order [ceil(Cout/32)][KW][nchunk][q 0..3][lane 0..63][4 floats]: the float4
+// lane l = (li, lh) of a wave feeds to the four v_mfma_f32_32x32x2_f32 of k-group q as B operand of column 32 t + li:
+// k = 32 c + 8 q + 4 lh .. + 3 (conv_gemm.hip: the same float4 its LDS weight tile hands that lane).  Columns >= Cout and channels
+// >= Cin are zero.  Runs once per weight tensor at load time.
+__global__ void f32_to_frag_kernel(const float* __restrict__ w, float4* __restrict__ frag, int Cout, int KW, int Cin, int nchunk, long long groups) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= groups) return;
+  const int lane = (int)(g & 63), q = (int)((g >> 6) & 3);
+  long long r = g >> 8;
+  const int c = (int)(r % nchunk); r /= nchunk;
+  const int j = (int)(r % KW);
+  const int t = (int)(r / KW);
+  const int n = t * 32 + (lane & 31);
+  const int k0 = c * 32 + q * 8 + (lane >> 5) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < Cout) {
+    const float* row = w + ((long long)n * KW + j) * Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (k0 + i < Cin) v[i] = row[k0 + i];
+  }
+  frag[g] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // ---- iSTFTNet tail (reference V/generator.py:107-113 + src/tools/stft.py:138-148)
 // x = leaky_relu(x, 0.01); x = ReflectionPad1d((1, 0))(x): frame 0 of the padded signal is frame 1 of the input.
 __global__ void reflect_lrelu_kernel(const float4* __restrict__ in, float4* __restrict__ out, long long n, int c4, float slope) {
@@ -560,6 +584,16 @@ const char* launch_x3_to_frag(const float* x3, float* frag, int Cout, int KW, in
   hipLaunchKernelGGL(x3_to_frag_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s,
                      reinterpret_cast<const uint4*>(x3), reinterpret_cast<uint4*>(frag), Cout, KW, nchunk, groups);
   return CHECK_LAUNCH("x3_to_frag");
+}
+
+const char* launch_f32_to_frag(const float* w, float* frag, int Cout, int KW, int Cin, hipStream_t s) {
+  if (!w || !frag) return "f32_to_frag: null pointer";
+  if (Cout <= 0 || KW <= 0 || Cin <= 0) return "f32_to_frag: bad dims";
+  const int nchunk = (Cin + 31) / 32;
+  const long long groups = (long long)((Cout + 31) / 32) * KW * nchunk * 256;
+  hipLaunchKernelGGL(f32_to_frag_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<float4*>(frag), Cout, KW,
+                     Cin, nchunk, groups);
+  return CHECK_LAUNCH("f32_to_frag");
 }
 
 const char* launch_reflect_lrelu(const float* in, float* out, int B, long long n, int C, float slope, hipStream_t s) {

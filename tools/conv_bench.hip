@@ -1,5 +1,6 @@
 // Micro-benchmark + self-check of conv_gemm on the shapes of the B = 32, T = 768 workload.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I e2e_tts_amd/csrc tools/conv_bench.hip e2e_tts_amd/csrc/conv_gemm.hip -o tools/bin/conv_bench
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I e2e_tts_amd/csrc tools/conv_bench.hip e2e_tts_amd/csrc/conv_gemm.hip e2e_tts_amd/csrc/small_kernels.hip -o tools/bin/conv_bench
+// Usage: conv_bench [reps] [name-filter | -] [f32 | f32f | x3 | x3f]   (f32f / x3f: weights in MFMA-fragment order)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -92,10 +93,11 @@ int main(int argc, char** argv) {
   const char* filter = argc > 2 && strcmp(argv[2], "-") ? argv[2] : nullptr;
   const int x3 = argc > 3 && (!strcmp(argv[3], "x3") || !strcmp(argv[3], "x3f"));
   const int frag = argc > 3 && !strcmp(argv[3], "x3f");
+  const int frag32 = argc > 3 && !strcmp(argv[3], "f32f");
   hipStream_t s;
   CK(hipStreamCreate(&s));
   // ---- correctness on small awkward shapes
-  if (!filter || x3) {
+  if (!filter || x3 || frag32) {
     Shape checks[] = {{"chk1", 2, 300, 80, 80, 5, 1, true, false, 0.1f}, {"chk2", 3, 777, 32, 32, 11, 5, true, true, 0.1f},
                       {"chk3", 1, 129, 128, 200, 3, 3, false, false, 1.0f}, {"chk4", 2, 64, 384, 1152, 1, 1, false, false, 1.0f},
                       {"chk5", 2, 1000, 64, 64, 7, 3, true, false, 0.1f}, {"chk6", 1, 50, 12, 20, 9, 1, false, false, 1.0f},
@@ -124,6 +126,12 @@ int main(int argc, char** argv) {
       ConvParams q = p; q.out = dref;
       if (x3) { p.w = dwx; p.x3 = 1; }
       if (frag) p.wfrag = dwf;
+      if (frag32) {
+        CK(hipMalloc(&dwf, x3_frag_bytes(c.Cout, c.KW, c.Cin)));
+        const char* fm = launch_f32_to_frag(dw, dwf, c.Cout, c.KW, c.Cin, s);
+        if (fm) { printf("%s\n", fm); return 1; }
+        p.wfrag = dwf;
+      }
       const char* m = launch_conv_gemm(p, s);
       if (m) { printf("%s: %s\n", c.name, m); return 1; }
       hipLaunchKernelGGL(naive_conv, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, q);
@@ -168,7 +176,9 @@ int main(int argc, char** argv) {
   {  // any finite bf16 pattern will do for timing: pack a random [2048][3*512] matrix once (covers every shape's footprint)
     std::vector<float> w((size_t)2048 * 3 * 512); fill(w, 9); for (auto& x : w) x *= 0.03f;
     auto px = pack_x3(w, 2048, 3, 512);
-    CK(hipMalloc(&dwx3, px.size() * 4 + (1 << 20))); CK(hipMemcpy(dwx3, px.data(), px.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dwx3, px.size() * 4 + (4 << 20)));  // the largest fragment image (ffn k9: 14.2 MB) must fit: timing reads it as wfrag
+    CK(hipMemset(dwx3, 0, px.size() * 4 + (4 << 20)));
+    CK(hipMemcpy(dwx3, px.data(), px.size() * 4, hipMemcpyHostToDevice));
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   double tot_ms = 0, tot_fl = 0;
@@ -179,7 +189,7 @@ int main(int argc, char** argv) {
     p.in_ld = c.Cin; p.out_ld = c.Cout; p.res_ld = c.Cout; p.in_bs = (long long)c.T * c.Cin; p.out_bs = (long long)c.T * c.Cout; p.res_bs = p.out_bs;
     p.in_slope = c.slope; p.act = c.res ? ACT_NONE : ACT_LRELU; p.act_slope = 0.1f; p.accumulate = c.acc; p.out_div = 1.f;
     p.x3 = x3; if (x3) p.w = dwx3;
-    if (frag) p.wfrag = dwx3;  // timing only: any finite bf16 pattern, same footprint
+    if (frag || frag32) p.wfrag = dwx3;  // timing only: any finite pattern, same footprint
     for (int i = 0; i < 2; ++i) { const char* m = launch_conv_gemm(p, s); if (m) { printf("%s: %s\n", c.name, m); return 1; } }
     CK(hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) launch_conv_gemm(p, s);

@@ -100,8 +100,18 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
 // CPI > 0 (KW == 1 launches on the fragment path, Cin a multiple of 32 CPI): a work item stages CPI 32-channel chunks at once, as
 //        CPI planes of the slab, and the loop walks them like taps.  A plain Linear has ONE tap per chunk, i.e. two workgroup
 //        barriers and a staging pass per 24 MFMAs of a wave; with CPI planes it is one per 24 CPI.  Same chunk order, same bits.
+// Waves per SIMD the register allocation must allow.  The exact-fp32 kernel on fragment-order weights keeps only its slab in LDS
+// (<= 28 KB), so a third workgroup would fit on the CU if the kernel stayed within 168 VGPRs (tuning knob E2ETTS_F32_OCC).
+// Measured (tools/conv_bench f32f, same box): 3 waves / SIMD gain 2 % on the k = 11 layers (141 -> 144 TFLOP/s) and lose 13 % on the k = 3
+// layers at 128 channels (the register cap spills 156 B / lane): left at 2.
+#ifndef E2ETTS_F32_OCC
+#define E2ETTS_F32_OCC 2
+#endif
+template <int BM, int BN, int MODE, bool BFRAG, int CPI>
+constexpr int conv_min_waves() { return (MODE == 0 && BFRAG && CPI == 0 && BM * BN <= 128 * 128) ? E2ETTS_F32_OCC : 2; }
+
 template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
+__global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
   constexpr bool K1 = CPI > 0;
   static_assert(!K1 || BFRAG, "multi-chunk items exist on the fragment path only");
   constexpr bool X3 = MODE != 0;

@@ -37,6 +37,7 @@ namespace {
 
 constexpr int LDK = 36;        // LDS row: 32 bf16 hi | 32 bf16 lo | 16 B pad = 36 words
 constexpr int MAX_HALO1 = 64;  // (KW - 1) * dil of conv1
+constexpr size_t PAIR_MAX_LDS = 160 * 1024;
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   const bf16x2 r = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32, round to nearest even
@@ -51,15 +52,24 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
   lo.y = pack_bf16(v.z - hz, v.w - hw);
 }
 
+// Workgroup = (BMI / WM) x (C / WN) wavefronts: 4 (256 threads; two or three workgroups per CU) at 32 / 64 / 128 channels, 8 (512 threads,
+// 2 x 4 waves of 64 x 64, ONE workgroup per CU) at 256 channels, whose intermediate [8 chunks][BMI + KW - 1 rows] x 144 B = 155-159 KB
+// fills the CU's LDS.  Same MFMA : weight-fragment ratio per wave as the 128-channel form (a 64-row tile would double the fragment
+// traffic per MFMA to ~43 B / clk / CU, against ~64 available from L2).
+template <int BMI, int C, int WM, int WN>
+constexpr int pair_threads() { return 64 * (BMI / WM) * (C / WN); }
+
 template <int BMI, int C, int WM, int WN, bool SPLIT, bool ACCUM>
-__global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(const PairParams p) {
+__global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) void resblock_pair_kernel(const PairParams p) {
   constexpr int NCH = C / 32;                  // 32-channel chunks (K of both convs, and N tiles of the intermediate)
   constexpr int NWN = C / WN;
   constexpr int MT = WM / 32, NT = WN / 32;
-  static_assert((BMI / WM) * NWN == 4, "4 wavefronts per workgroup");
-  constexpr int AROWS = (BMI + MAX_HALO1 + 31) / 32;  // slab rows staged per thread (upper bound)
+  constexpr int NWAVE = (BMI / WM) * NWN;
+  static_assert(NWAVE == 4 || NWAVE == 8, "4 or 8 wavefronts per workgroup");
+  constexpr int SROWS = NWAVE * 8;             // slab rows one staging pass of the workgroup covers (8 threads per 32-channel row)
+  constexpr int AROWS = (BMI + MAX_HALO1 + SROWS - 1) / SROWS;  // slab rows staged per thread (upper bound)
   constexpr int ELD = WN + 4;                          // epilogue patch row stride (floats)
-  static_assert(4 * 16 * ELD <= BMI * LDK, "epilogue patches must fit in the region");
+  static_assert(NWAVE * 16 * ELD <= NCH * BMI * LDK, "epilogue patches must fit in the region (>= the intermediate: NCH x (BMI + KW - 1) rows)");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int KW = p.KW, dil = p.dil;
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
     const int x0 = tile * BMO - pad2 - pad1;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int r = lrow + i * 32;
+      const int r = lrow + i * SROWS;
       const int g = x0 + r;
       aok[i] = r < srows && g >= 0 && g < p.T;
       const int gc = min(max(g, 0), p.T - 1);
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void resblock_pair_kernel(con
   auto store_a = [&]() {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int r = lrow + i * 32;
+      const int r = lrow + i * SROWS;
       if (r < srows) {
         float4 v = aok[i] ? areg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         v.x = fmaxf(v.x, v.x * p.slope); v.y = fmaxf(v.y, v.y * p.slope);
@@ -346,13 +356,14 @@ const char* launch_pair_cfg(const PairParams& p, hipStream_t s) {
   const int BMO = BMI - (p.KW - 1);
   const size_t words = (size_t)std::max((BMI + halo1) * LDK, (C / 32) * (BMI + p.KW - 1) * LDK);
   const size_t lds = words * sizeof(float);
-  if (lds > 80 * 1024) return "resblock_pair: LDS region exceeds 80 KiB";
+  if (lds > PAIR_MAX_LDS) return "resblock_pair: LDS region exceeds the CU's 160 KiB";
   const int mtiles = (p.T + BMO - 1) / BMO;
   dim3 grid((mtiles + 7) / 8 * 8, p.B);  // a multiple of 8 (see the XCD-aware order in the kernel); extra blocks exit
+  constexpr int NTHR = pair_threads<BMI, C, WM, WN>();
   if (p.accumulate)
-    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, true>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, true>), grid, dim3(NTHR), lds, s, p);
   else
-    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, false>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, false>), grid, dim3(NTHR), lds, s, p);
   return hipGetLastError() == hipSuccess ? nullptr : "resblock_pair: launch failed";
 }
 
@@ -360,10 +371,11 @@ template <int BMI, int C, int WM, int WN>
 const char* launch_pair_mode(const PairParams& p, hipStream_t s) {
   static bool attr_done = false;  // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    const int cap = C == 256 ? (int)PAIR_MAX_LDS : 80 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     attr_done = true;
   }
   return p.mode == 1 ? launch_pair_cfg<BMI, C, WM, WN, true>(p, s) : launch_pair_cfg<BMI, C, WM, WN, false>(p, s);
@@ -372,7 +384,9 @@ const char* launch_pair_mode(const PairParams& p, hipStream_t s) {
 }  // namespace
 
 bool resblock_pair_supported(int C, int KW, int dil) {
-  return (C == 32 || C == 64 || C == 128) && (KW & 1) && KW >= 3 && KW <= 15 && dil >= 1 && dil * (KW - 1) <= MAX_HALO1;
+  if (!((C == 32 || C == 64 || C == 128 || C == 256) && (KW & 1) && KW >= 3 && KW <= 15 && dil >= 1 && dil * (KW - 1) <= MAX_HALO1)) return false;
+  // 256 channels: the intermediate [8][128 + KW - 1] x 144 B must fit the CU's LDS
+  return C != 256 || (size_t)(C / 32) * (128 + KW - 1) * LDK * 4 <= PAIR_MAX_LDS;
 }
 
 double resblock_pair_flops(const PairParams& p) { return 2.0 * 2.0 * p.B * (double)p.T * p.C * p.KW * p.C; }
@@ -394,6 +408,7 @@ const char* launch_resblock_pair(const PairParams& p, hipStream_t s) {
   if (p.x == p.out) return "resblock_pair: in-place is not possible (tiles read their neighbours' rows)";
   if (p.C == 32) return launch_pair_mode<256, 32, 64, 32>(p, s);
   if (p.C == 64) return launch_pair_mode<256, 64, 64, 64>(p, s);
+  if (p.C == 256) return launch_pair_mode<128, 256, 64, 64>(p, s);
   return launch_pair_mode<128, 128, 64, 64>(p, s);
 }
 

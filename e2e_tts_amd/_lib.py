@@ -355,9 +355,11 @@ class Engine:
         self._check(self.lib.e2etts_set_ragged(self._h, 1 if on else 0), "e2etts_set_ragged")
 
     @_locked
-    def set_fused_resblocks(self, on: bool = True):
-        """bf16 modes: each ResBlock conv pair at 32 / 64 / 128 channels as one kernel (default on); results are bit-identical."""
-        self._check(self.lib.e2etts_set_fused_resblocks(self._h, 1 if on else 0), "e2etts_set_fused_resblocks")
+    def set_fused_resblocks(self, on=True):
+        """bf16 modes.  True / 2 (default): ResBlock conv pairs at 32 .. 256 channels as one kernel each, and whole k = 3 ResBlocks at
+        32 / 64 channels as one kernel; 1: pairs only; False / 0: two convolution launches per pair.  Results are bit-identical."""
+        level = 2 if on is True else (0 if on is False else int(on))
+        self._check(self.lib.e2etts_set_fused_resblocks(self._h, level), "e2etts_set_fused_resblocks")
 
     # ---- long-form / streaming vocoder
     def vocoder_stream(self, chunks, B: int, want_pcm: bool = False):

@@ -101,8 +101,9 @@ struct e2etts_engine {
   // fused ResBlock pairs (resblock_pair.hip): conv1's fragment-order image followed by conv2's, per [stage * n_kernels + j][m];
   // stage_fused[i]: every pair of stage i can run fused (channels 32 / 64 / 128)
   std::vector<std::vector<float*>> rb_pair_frag;
+  std::vector<float*> rb_frag_base;  // the allocations rb_pair_frag points into (one per ResBlock)
   std::vector<char> stage_fused;
-  int fuse_pairs = 1;  // e2etts_set_fused_resblocks
+  int fuse_pairs = 2;  // e2etts_set_fused_resblocks: 0 off, 1 pairs, 2 pairs + whole k = 3 ResBlocks
 
   // workspace
   DevBuf ids, lens64, lens32, spk, xa, xb, xs, xp, tmp, qkv, att, hid, p1, p2;
@@ -278,9 +279,9 @@ void free_frags(e2etts_engine* e) {
     (void)hipFree(kv.second);
   }
   e->frag_of.clear();
-  for (auto& v : e->rb_pair_frag)
-    for (float* f : v)
-      if (f) (void)hipFree(f);
+  for (float* f : e->rb_frag_base)
+    if (f) (void)hipFree(f);
+  e->rb_frag_base.clear();
   e->rb_pair_frag.clear();
   e->stage_fused.clear();
   e->dev_bytes -= e->frag_bytes;
@@ -531,12 +532,16 @@ int bind_vocoder(e2etts_engine* e) {
     for (int j = 0; j < c.voc_n_kernels && fusable; ++j) {
       const int idx = i * c.voc_n_kernels + j;
       const int k = c.voc_rb_kernel[j];
+      // ONE allocation per ResBlock: conv1 | conv2 of pair 0, pair 1, ... contiguous, so that the whole-ResBlock kernel
+      // (resblock_chain.hip) walks all of them through one buffer descriptor; rb_pair_frag[idx][m] points at pair m
+      const size_t one = x3_frag_bytes((int)ch, k, (int)ch);
+      float* base = nullptr;
+      HIPCHK(e, hipMalloc(&base, 2 * one * c.voc_n_dil));
+      e->dev_bytes += 2 * one * c.voc_n_dil;
+      e->frag_bytes += 2 * one * c.voc_n_dil;
+      e->rb_frag_base.push_back(base);
       for (int m = 0; m < c.voc_n_dil; ++m) {
-        const size_t one = x3_frag_bytes((int)ch, k, (int)ch);
-        float* f = nullptr;
-        HIPCHK(e, hipMalloc(&f, 2 * one));
-        e->dev_bytes += 2 * one;
-        e->frag_bytes += 2 * one;
+        float* f = base + (size_t)m * 2 * (one / 4);
         e->rb_pair_frag[idx].push_back(f);
         KCHK(e, launch_x3_to_frag(e->rb_c1[idx][m].wx3, f, (int)ch, k, (int)ch, e->stream));
         KCHK(e, launch_x3_to_frag(e->rb_c2[idx][m].wx3, f + one / 4, (int)ch, k, (int)ch, e->stream));
@@ -981,7 +986,24 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       const int k = c.voc_rb_kernel[j];
       const float* cur = XU;
       const bool fused = e->fuse_pairs && e->voc_precision != E2ETTS_PRECISION_FP32 && e->stage_fused[i];
-      for (int m = 0; m < c.voc_n_dil && fused; ++m) {
+      // the whole ResBlock in one launch (resblock_chain.hip) where it exists: kernel size 3 at 32 / 64 channels
+      const bool chained = fused && e->fuse_pairs >= 2 && resblock_chain_supported(co, k, c.voc_rb_dil[j], c.voc_n_dil);
+      if (chained) {
+        ChainParams q;
+        q.x = XU; q.wfrag = e->rb_pair_frag[idx][0]; q.out = S;
+        for (int m = 0; m < 3; ++m) { q.b1[m] = e->rb_c1[idx][m].b; q.b2[m] = e->rb_c2[idx][m].b; q.dil[m] = c.voc_rb_dil[j][m]; }
+        q.act_rows = act_stage[i + 1];
+        q.B = B; q.T = (int)n; q.C = co; q.KW = k;
+        q.x_bs = q.out_bs = (long long)n * co;
+        q.slope = 0.1f; q.mode = e->voc_precision;
+        q.accumulate = j > 0;
+        if (j == c.voc_n_kernels - 1 && q.accumulate) q.out_div = (float)c.voc_n_kernels;
+        char nm[48];
+        snprintf(nm, sizeof nm, "resblock_chain_%d", co);
+        ProfScope ps(e, nm, resblock_chain_flops(q), resblock_chain_bytes(q));
+        KCHK(e, launch_resblock_chain(q, e->stream));
+      }
+      for (int m = 0; m < c.voc_n_dil && fused && !chained; ++m) {
         // the whole pair in one launch (resblock_pair.hip); x and out must differ, so the running x ping-pongs CUR / T1
         const bool last = m == c.voc_n_dil - 1;
         PairParams q;
@@ -1479,10 +1501,11 @@ int e2etts_set_ragged(e2etts_engine* e, int enable) {
   return E2ETTS_OK;
 }
 
-int e2etts_set_fused_resblocks(e2etts_engine* e, int enable) {
+int e2etts_set_fused_resblocks(e2etts_engine* e, int level) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
-  e->fuse_pairs = enable != 0;
+  if (level < 0 || level > 2) return e->fail(E2ETTS_EINVAL, "fusion level must be 0 (off), 1 (pairs) or 2 (pairs + whole k = 3 ResBlocks)");
+  e->fuse_pairs = level;
   return E2ETTS_OK;
 }
 

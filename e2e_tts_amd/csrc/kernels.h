@@ -100,6 +100,28 @@ const char* launch_resblock_pair(const PairParams& p, hipStream_t s);
 double resblock_pair_flops(const PairParams& p);
 double resblock_pair_bytes(const PairParams& p);
 
+// A whole ResBlock1 of kernel size 3 (three pairs, dilations dil[0..2]) in one launch (resblock_chain.hip):
+// out = x_3 with x_{m+1} = c2_m(lrelu(c1_m(lrelu(x_m)) + b1_m)) + b2_m + x_m, optionally (out_old + x_3) / out_div.
+struct ChainParams {
+  const float* x = nullptr;        // [B, T, C] channels-last
+  const float* wfrag = nullptr;    // fragment-order images, contiguous: conv1 | conv2 of pair 0, then pair 1, then pair 2
+  const float* b1[3] = {nullptr, nullptr, nullptr};
+  const float* b2[3] = {nullptr, nullptr, nullptr};
+  float* out = nullptr;            // [B, T, C], must not alias x
+  const int32_t* act_rows = nullptr;
+  int B = 0, T = 0, C = 0, KW = 3;
+  int dil[3] = {1, 3, 5};
+  long long x_bs = 0, out_bs = 0;
+  float slope = 0.1f;
+  int accumulate = 0;
+  float out_div = 1.0f;
+  int mode = 1;                    // 1: bf16x3 split precision, 2: plain bf16
+};
+bool resblock_chain_supported(int C, int KW, const int* dil, int n_dil);
+const char* launch_resblock_chain(const ChainParams& p, hipStream_t s);
+double resblock_chain_flops(const ChainParams& p);
+double resblock_chain_bytes(const ChainParams& p);
+
 // split-precision weight image -> MFMA-fragment order (ConvParams::wfrag)
 const char* launch_x3_to_frag(const float* x3, float* frag, int Cout, int KW, int Cin, hipStream_t s);
 size_t x3_frag_bytes(int Cout, int KW, int Cin);

@@ -179,10 +179,11 @@ int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decod
  * e2etts_vocoder always compute the full padded tensors (their padded rows match the reference's). */
 int e2etts_set_ragged(e2etts_engine* engine, int enable);
 
-/* Fused ResBlock pairs (default on).  In the bf16 modes each (conv k, dilation d -> leaky ReLU -> conv k -> + x) pair of
- * HiFi-GAN's ResBlock1 (reference V/layers.py:33-40) at 32 / 64 / 128 channels runs as ONE kernel whose intermediate
- * stays in LDS; enable == 0 runs it as two convolution launches.  Both forms produce bit-identical output. */
-int e2etts_set_fused_resblocks(e2etts_engine* engine, int enable);
+/* Fused ResBlocks (bf16 modes).  level 1: each (conv k, dilation d -> leaky ReLU -> conv k -> + x) pair of HiFi-GAN's ResBlock1
+ * (reference V/layers.py:33-40) at 32 / 64 / 128 / 256 channels runs as ONE kernel whose intermediate stays in LDS.  level 2
+ * (default): additionally a whole kernel-size-3 ResBlock1 (its three pairs) at 32 / 64 channels runs as one kernel whose residual
+ * stream stays in registers.  level 0: two convolution launches per pair.  All three produce bit-identical output. */
+int e2etts_set_fused_resblocks(e2etts_engine* engine, int level);
 
 /* Per-kernel-class timing with HIP events on the engine's stream (bench.py roofline leg).
  * enable != 0 starts recording (and clears counters); e2etts_profile_read fills up to `cap` records. */

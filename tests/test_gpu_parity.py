@@ -576,8 +576,11 @@ def test_ragged_synthesize_is_bit_identical_on_valid_samples(name):
 
 @pytest.mark.parametrize("name", ["tiny_b3", "full_b3", "c3_mixed"])
 def test_fused_resblock_pairs_are_bit_identical(name):
-    """resblock_pair.hip (intermediate in LDS) against the same pair as two conv_gemm launches: same arithmetic in the same
-    order, so the PCM and the fp32 waveform must be equal bit for bit -- padded (vocoder) and ragged (synthesize)."""
+    """resblock_pair.hip (a pair's intermediate in LDS; 32 .. 256 channels) and resblock_chain.hip (a whole k = 3 ResBlock, residual
+    stream in registers; 32 / 64 channels) against the same pairs as two conv_gemm launches each: same arithmetic in the same order,
+    so the PCM and the fp32 waveform must be equal bit for bit -- padded (vocoder) and ragged (synthesize).  The tiny config's
+    stages are 32 / 16 / 8 / 4 channels wide (only its first takes the fused kernels); the default config's 256 / 128 / 64 / 32
+    exercise every fused form."""
     g = load_golden(name)
     cfg, eng = engine_for(g, name)
     d, p, e = (float(x) for x in g["controls"])
@@ -587,20 +590,21 @@ def test_fused_resblock_pairs_are_bit_identical(name):
         for prec in ("bf16x3", "bf16"):
             eng.set_precision(prec)
             out = {}
-            for fused in (False, True):
-                eng.set_fused_resblocks(fused)
+            for level in (0, 1, 2):   # two launches per pair / fused pairs / fused pairs + whole k = 3 ResBlocks
+                eng.set_fused_resblocks(level)
                 eng.set_ragged(False)
                 r = eng.acoustic(g["ids"], g["lens"], spk, d, p, e, want=("mel_lens",))
                 wav, pcm = eng.vocoder(None, r["B"], r["T"], pcm=True)
                 eng.set_ragged(True)
                 rag, mel_lens, _ = eng.synthesize(g["ids"], g["lens"], spk, d, p, e)
-                out[fused] = (wav, pcm, rag, mel_lens)
-            np.testing.assert_array_equal(out[True][0], out[False][0])
-            np.testing.assert_array_equal(out[True][1], out[False][1])
-            for b, n in enumerate(out[True][3] * hop):
-                np.testing.assert_array_equal(out[True][2][b, :n], out[False][2][b, :n])
+                out[level] = (wav, pcm, rag, mel_lens)
+            for level in (1, 2):
+                np.testing.assert_array_equal(out[level][0], out[0][0])
+                np.testing.assert_array_equal(out[level][1], out[0][1])
+                for b, n in enumerate(out[level][3] * hop):
+                    np.testing.assert_array_equal(out[level][2][b, :n], out[0][2][b, :n])
             if prec == "bf16x3" and "wav" in g:
-                assert mean_l1(out[True][0], g["wav"]) < WAV_L1
+                assert mean_l1(out[2][0], g["wav"]) < WAV_L1
     finally:
         eng.set_fused_resblocks(True)
         eng.set_precision("bf16x3")

@@ -342,9 +342,10 @@ class Engine:
         return w
 
     @_locked
-    def set_precision(self, vocoder: str = "bf16x3", decoder: Optional[str] = None):
-        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, the default) for the vocoder and for the
-        decoder + mel_linear + postnet (defaults to the vocoder's choice).  Encoder / variance adaptor: always fp32."""
+    def set_precision(self, vocoder: str = "fp32", decoder: Optional[str] = None):
+        """'fp32' (exact fp32 MFMA: the engine's default and the reference's arithmetic) or 'bf16x3' (split-precision bf16 MFMA: the
+        opt-in fast mode, PCM within 1 LSB of the reference's) for the vocoder and for the decoder + mel_linear + postnet (defaults
+        to the vocoder's choice).  Encoder / variance adaptor: always fp32."""
         modes = {"fp32": 0, "bf16x3": 1, "bf16": 2}   # 'bf16' (plain, vocoder only) is the long-form streaming config's arithmetic
         dec = decoder if decoder is not None else ("bf16x3" if vocoder == "bf16" else vocoder)
         self._check(self.lib.e2etts_set_precision(self._h, modes[vocoder], modes[dec]), "e2etts_set_precision")

@@ -117,7 +117,7 @@ struct e2etts_engine {
   int64_t* h_mel = nullptr;  // pinned
   int last_B = 0, last_L = 0, last_T = 0, voc_B = 0, voc_T = 0;
   bool have_acoustic = false, have_wav = false;
-  int voc_precision = 1;  // 0: fp32 MFMA, 1: bf16x3 split-precision MFMA, 2: plain bf16 (E2ETTS_PRECISION_*)
+  int voc_precision = 0;  // 0: fp32 MFMA (default: the reference's arithmetic), 1: bf16x3 split-precision MFMA, 2: plain bf16 (E2ETTS_PRECISION_*)
   // streaming vocoder (e2etts_vocoder_stream_*): trailing mel frames kept as context / not yet emitted
   DevBuf st_carry, st_win;
   int st_B = 0, st_carry_n = 0, st_halo = 0, st_emit_n = 0, st_emit_off = 0, st_win_n = 0;
@@ -125,7 +125,7 @@ struct e2etts_engine {
   bool st_open = false, st_done = false;
   int ragged = 1;         // synthesize(): skip rows of shorter utterances that no valid output sample depends on
   DevBuf actbuf;          // [2 + voc_stages + 1][B] int32 row limits
-  int dec_precision = 1;  // same choice for decoder + mel_linear + postnet (encoder / variance adaptor: always fp32)
+  int dec_precision = 0;  // same choice for decoder + mel_linear + postnet (encoder / variance adaptor: always fp32)
 
   // profiling
   bool prof_on = false;

@@ -162,10 +162,12 @@ int e2etts_vocoder_stream_fetch(e2etts_engine* engine, float* wav_out, int16_t* 
 
 /* Arithmetic of the convolutions / projections of (a) the vocoder and (b) the decoder + mel_linear + postnet.
  * The encoder and the variance adaptor are always exact fp32: the duration / pitch / energy decisions taken there
- * must be bit-exact, and nothing downstream of the length regulator is discrete.  E2ETTS_PRECISION_FP32: v_mfma_f32_32x32x2_f32.  E2ETTS_PRECISION_BF16X3 (default):
- * every fp32 operand is split into bf16 hi + lo and the product keeps hi*hi + hi*lo + lo*hi on the bf16 matrix
- * pipe with fp32 accumulation -- ~16 significant bits per operand; measured waveform error vs fp64: mean-L1 9e-7
- * (fp32: 6e-8; plain bf16: 5e-4; parity bar: 1e-4). */
+ * must be bit-exact, and nothing downstream of the length regulator is discrete.
+ * E2ETTS_PRECISION_FP32 (default -- the reference's arithmetic): v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain.
+ * E2ETTS_PRECISION_BF16X3 (opt-in fast mode, 2.7 x the throughput): every fp32 operand is split into bf16 hi + lo and the
+ * product keeps hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation -- ~16 significant bits per operand;
+ * measured against the reference's own outputs (bench.py `split_precision_mode`): wav mean-L1 1.1e-6 .. 1.3e-6 (fp32: 1.3e-7;
+ * plain bf16: 5e-4; parity bar: 1e-4), int16 PCM within 1 LSB on 100 % of samples, discrete outputs untouched. */
 #define E2ETTS_PRECISION_FP32 0
 #define E2ETTS_PRECISION_BF16X3 1
 #define E2ETTS_PRECISION_BF16 2 /* vocoder only: hi x hi product alone (plain bf16 operands, fp32 accumulation): the arithmetic

@@ -413,20 +413,22 @@ def test_reload_and_mode_switches_leave_no_stale_state():
     eng.load_weights(blobs[1])                              # reload on a live engine
     assert same(run(eng), fresh[1])
     eng.load_weights(blobs[0])
-    base = run(eng)
+    base = run(eng)                                         # the engine's default arithmetic: exact fp32
     assert same(base, fresh[0])
-    eng.set_precision("fp32")
-    exact = run(eng)
     eng.set_precision("bf16x3")
-    assert same(run(eng), base)
-    assert all(np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2 for a, b in zip(exact, base))
-    eng.set_fused_resblocks(False)
-    assert same(run(eng), base)                             # fused == two-launch form, bit for bit
-    eng.set_fused_resblocks(True)
+    fast = run(eng)
+    eng.set_precision("fp32")
+    assert same(run(eng), base)                             # away and back: the same bits
+    assert all(np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2 for a, b in zip(base, fast))
+    eng.set_precision("bf16x3")                             # the fused ResBlock kernels exist in the bf16 modes
+    assert same(run(eng), fast)
+    for level in (0, 1, 2):
+        eng.set_fused_resblocks(level)
+        assert same(run(eng), fast)                         # fused == two-launch form, bit for bit
     eng.set_ragged(False)
-    assert same(run(eng), base)
+    assert same(run(eng), fast)
     eng.set_ragged(True)
-    assert same(run(eng), base)
+    assert same(run(eng), fast)
     eng.close()
     # half blobs
     only_ac = Engine(dims, 0)

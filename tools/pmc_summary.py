@@ -31,6 +31,9 @@ def kernel_class(name: str):
     m = re.search(r"resblock_pair_kernel<\d+, (\d+)", name)
     if m:
         return "resblock_pair_" + m.group(1)
+    m = re.search(r"resblock_chain_kernel<\d+, (\d+)", name)
+    if m:
+        return "resblock_chain_" + m.group(1)
     for key, cls in (("rel_attention_kernel", "rel_attention"), ("attention_x3_kernel", "attention_x3"), ("attention_kernel", "attention"),
                      ("layernorm_kernel", "layernorm"), ("conv_post_kernel", "conv_post"), ("dwconv_swish_kernel", "dwconv_swish"),
                      ("glu_kernel", "glu")):
@@ -69,8 +72,9 @@ def main():
     os.makedirs(dst, exist_ok=True)
     traffic = {}
     lines = [f"# {title}", "",
-             "Separate `rocprofv3 --pmc` passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (counters only, no trace",
-             "domains), summarised by tools/pmc_summary.py.  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs):",
+             "Separate `rocprofv3 --pmc` passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` -- once in the default",
+             "exact-fp32 arithmetic (classes conv_gemm_*) and once with `--precision bf16x3` (classes conv_x3_*, resblock_*) -- counters only, no",
+             "trace domains, summarised by tools/pmc_summary.py.  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs):",
              "GRBM_GUI_ACTIVE is summed over the 8 XCDs, a bf16 MFMA counts its own 32 cycles, so 1.00 = the dense peak AT THE CLOCK HELD.",
              "clock = GRBM_GUI_ACTIVE / 8 / kernel time.  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B reads as 64 B).", "",
              "| kernel | launches | clock GHz | MFMA busy | WAIT_ANY/WAVE | WAIT_INST_ANY/WAVE | ACTIVE/WAVE | FETCH_SIZE B/launch (raw) | WRITE_SIZE B/launch | HBM B/launch |",

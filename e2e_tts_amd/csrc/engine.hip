@@ -985,7 +985,11 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       const int idx = i * c.voc_n_kernels + j;
       const int k = c.voc_rb_kernel[j];
       const float* cur = XU;
-      const bool fused = e->fuse_pairs && e->voc_precision != E2ETTS_PRECISION_FP32 && e->stage_fused[i];
+      bool fused = e->fuse_pairs && e->voc_precision != E2ETTS_PRECISION_FP32 && e->stage_fused[i];
+      // 256 channels: the fused pair runs ONE 512-thread workgroup per CU on tiles of ~118-126 rows; with fewer tiles than CUs (small
+      // batches: 52 tiles at B = 1, T = 768) the two-launch form on 64 x 64 tiles fills the chip better (B = 1: 5.99 vs 6.45 ms per
+      // utterance).  Both forms give the same bits, so the choice is invisible in the output.
+      if (fused && co == 256 && (long long)B * (n / 128) < 256) fused = false;
       // the whole ResBlock in one launch (resblock_chain.hip) where it exists: kernel size 3 at 32 / 64 channels
       const bool chained = fused && e->fuse_pairs >= 2 && resblock_chain_supported(co, k, c.voc_rb_dil[j], c.voc_n_dil);
       if (chained) {

@@ -20,8 +20,11 @@
 //   --conv2-->  output rows [o0, o0 + BMI - (KW-1)).   The (KW-1)/BMI recompute is the price of the fusion (4 % at k = 11,
 //   BMI = 256).  Intermediate rows outside [0, T) are ZERO (conv2's zero padding), not conv1 of padding.
 // LDS: one region, first the x slab of one 32-channel chunk [(BMI + (KW-1) d) x 36 words], then -- conv1's accumulators
-// being complete -- overwritten by the intermediate [C/32][(BMI + KW - 1) x 36 words], then by the epilogue's transpose
-// patches.
+// being complete -- overwritten by the intermediate [C/32][(BMI + KW - 1) x 36 words].
+// MFMA orientation (round 2): the TRANSPOSED product D^T = W . X^T (weight fragment = A operand, activation rows = B), which puts a
+// POSITION on each accumulator lane and four consecutive channels on each register quad: the intermediate is written with packed
+// converts and 8-byte LDS stores (instead of a 2-byte store and a scalar convert per element), and the output epilogue fills its
+// row-major LDS patches with one ds_write_b128 per quad.  Bits are unchanged by the swap.
 #include <algorithm>
 #include <type_traits>
 
@@ -68,8 +71,6 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
   static_assert(NWAVE == 4 || NWAVE == 8, "4 or 8 wavefronts per workgroup");
   constexpr int SROWS = NWAVE * 8;             // slab rows one staging pass of the workgroup covers (8 threads per 32-channel row)
   constexpr int AROWS = (BMI + MAX_HALO1 + SROWS - 1) / SROWS;  // slab rows staged per thread (upper bound)
-  constexpr int ELD = WN + 4;                          // epilogue patch row stride (floats)
-  static_assert(NWAVE * 16 * ELD <= NCH * BMI * LDK, "epilogue patches must fit in the region (>= the intermediate: NCH x (BMI + KW - 1) rows)");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int KW = p.KW, dil = p.dil;
@@ -188,13 +189,17 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
       for (int n = 0; n < NT; ++n) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+          // TRANSPOSED product D^T = W . X^T: the weight fragment is the A operand (rows = output channels), the activation rows
+          // are B (columns = positions) -- the operand images are the same either way and so are the bits (the terms keep
+          // conv_gemm's order: x_lo w_hi, x_hi w_lo, x_hi w_hi).  An accumulator lane then holds ONE position and, per register
+          // quad, four consecutive channels: both epilogues work on float4 / packed pairs with no transpose through LDS.
           const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[P][ks][n][0]);
           if constexpr (SPLIT) {
             const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[P][ks][n][1]);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
           }
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
         }
         if constexpr (!DEEP) {
           // keep the request right behind the MFMAs that free its registers (left alone, hipcc sinks all requests to the end
@@ -219,104 +224,111 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
     mma_tap(std::integral_constant<int, P0>{}, a0 + j * row_step, nconv_end, nchunk_end, 0);  // j == KW - 1
   };
 
-  // ---- epilogue 1: intermediate = lrelu(acc + b1) (zero outside [0, T)), split, into LDS as conv2's A operand
-  // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  float bias1[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) bias1[n] = p.b1[wn * WN + n * 32 + li];
+  // ---- epilogue 1: intermediate = lrelu(acc + b1) (zero outside [0, T)), split, into LDS as conv2's operand image.
+  // Accumulator layout of the transposed product: lane (li, lh) = position li of the 32-position tile, register 4 q + i = channel
+  // 8 q + 4 lh + i of the 32-channel tile: four consecutive channels of one position = 8 bytes of the hi half and 8 of the lo half
+  // of that position's image row (two ds_write_b64, packed v_cvt_pk_bf16_f32).
   auto epilogue1 = [&](int tile) {
     const int i0 = tile * BMO - pad2;
-    unsigned short* inter = reinterpret_cast<unsigned short*>(smem);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int chunk = wn * NT + n;
+      float4 bq[4];
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(p.b1 + wn * WN + n * 32 + 8 * q + 4 * lh);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int g = i0 + row;
-          float v = acc[m][n][r] + bias1[n];
-          v = fmaxf(v, v * p.slope);
-          v = (g >= 0 && g < p.T) ? v : 0.f;
-          const __bf16 h = (__bf16)v;
-          const __bf16 l = (__bf16)(v - (float)h);
-          unsigned short* dst = inter + ((chunk * irows + row) * LDK) * 2 + li;
-          dst[0] = __builtin_bit_cast(unsigned short, h);
-          if constexpr (SPLIT) dst[32] = __builtin_bit_cast(unsigned short, l);
-          acc[m][n][r] = 0.f;
+      for (int m = 0; m < MT; ++m) {
+        const int row = wm * WM + m * 32 + li;
+        const int g = i0 + row;
+        const bool ok = g >= 0 && g < p.T;
+        float* dst = smem + (chunk * irows + row) * LDK + 2 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4] = {acc[m][n][4 * q] + bq[q].x, acc[m][n][4 * q + 1] + bq[q].y, acc[m][n][4 * q + 2] + bq[q].z, acc[m][n][4 * q + 3] + bq[q].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = fmaxf(v[i], v[i] * p.slope);
+            v[i] = ok ? v[i] : 0.f;
+            acc[m][n][4 * q + i] = 0.f;
+          }
+          uint2 hi;
+          hi.x = pack_bf16(v[0], v[1]);
+          hi.y = pack_bf16(v[2], v[3]);
+          *reinterpret_cast<uint2*>(dst + 4 * q) = hi;
+          if constexpr (SPLIT) {
+            const float h0 = __builtin_bit_cast(float, hi.x << 16), h1 = __builtin_bit_cast(float, hi.x & 0xffff0000u);
+            const float h2 = __builtin_bit_cast(float, hi.y << 16), h3 = __builtin_bit_cast(float, hi.y & 0xffff0000u);
+            uint2 lo;
+            lo.x = pack_bf16(v[0] - h0, v[1] - h1);
+            lo.y = pack_bf16(v[2] - h2, v[3] - h3);
+            *reinterpret_cast<uint2*>(dst + 16 + 4 * q) = lo;
+          }
         }
+      }
     }
   };
 
-  // ---- epilogue 2: out = acc + b2 + x (+ out, / div), float4 through wave-private transpose patches
-  constexpr int LPR = WN / 4, RPP = 64 / LPR, PASSES = 16 / RPP;
+  // ---- epilogue 2: out = acc + b2 + x (+ out, / div).  Global memory wants whole rows per wave instruction (16 lanes x 16 B = one
+  // 256-byte row segment), the accumulators hold a position per lane: each 32-position block goes through a wave-private LDS patch
+  // [32 positions][WN channels] -- written as one ds_write_b128 per register quad, read back with the lanes along the channels.
+  // (Straight float4 I/O from the accumulator layout -- 32 B per row and instruction -- was measured 8-27 % slower per pair.)
+  constexpr int ELD = WN + 4;                          // patch row stride (floats): a 16-lane group of b128 stores covers all 64 banks once
+  static_assert(NWAVE * 32 * ELD <= NCH * BMI * LDK, "epilogue patches must fit in the region (>= the intermediate: NCH x (BMI + KW - 1) rows)");
+  constexpr int LPR = WN / 4, RPP = 64 / LPR, PASSES = 32 / RPP;
   const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
   const int ecol = wn * WN + pc4;
   const float4 bias2 = *reinterpret_cast<const float4*>(p.b2 + ecol);
   auto epilogue2 = [&](int tile) {
     const int o0 = tile * BMO;
-    const int t_end = min(o0 + BMO, p.T);  // rows this tile owns
-    float* patch = smem + wave * (16 * ELD);
+    const int t_end = min(o0 + BMO, p.T);  // rows this tile owns (tile rows >= BMO are the recomputed overlap)
+    float* patch = smem + wave * (32 * ELD);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      float4 resv[2][PASSES];  // residual rows of this 32-row block, requested before its transposes
+      const int tb = o0 + wm * WM + m * 32;   // first output row of this 32-position block
+      float4 resv[PASSES];  // residual rows of the block, requested before its transposes
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-          const int t = min(o0 + wm * WM + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
-          resv[hh][ps] = *reinterpret_cast<const float4*>(x_b + (long long)t * C + ecol);
-        }
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        float4 accv[PASSES];  // accumulate mode: what the 16 output rows of this half hold now
-        if constexpr (ACCUM) {
-#pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) {
-            const int t = min(o0 + wm * WM + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
-            accv[ps] = *reinterpret_cast<const float4*>(out_b + (long long)t * C + ecol);
-          }
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
-            const int r = hh * 8 + rr;
-            const int row = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lh;
-            patch[row * ELD + n * 32 + li] = acc[m][n][r];
-          }
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int t = min(tb + ps * RPP + prow, p.T - 1);
+        resv[ps] = *reinterpret_cast<const float4*>(x_b + (long long)t * C + ecol);
+      }
+      float4 accv[PASSES];  // accumulate mode: what the output rows hold now
+      if constexpr (ACCUM) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
-          const int row = ps * RPP + prow;
-          const int t = o0 + wm * WM + m * 32 + hh * 16 + row;
-          float4 v = *reinterpret_cast<const float4*>(patch + row * ELD + pc4);
-          v.x += bias2.x; v.y += bias2.y; v.z += bias2.z; v.w += bias2.w;
-          const float4 rv = resv[hh][ps];
-          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-          if constexpr (ACCUM) {
-            const float4 ov = accv[ps];
-            v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
-            if (p.out_div != 1.0f) {
-              v.x = v.x / p.out_div; v.y = v.y / p.out_div; v.z = v.z / p.out_div; v.w = v.w / p.out_div;
-            }
-          }
-          // streaming store: this kernel never reads the tile back, and keeping it out of the way leaves the x rows (slab halo of the
-          // neighbour tile, residual re-read) in L2
-          if (t < t_end) {
-            typedef float f32x4_t __attribute__((ext_vector_type(4)));
-            const f32x4_t nv = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(nv, reinterpret_cast<f32x4_t*>(out_b + (long long)t * C + ecol));
-          }
+          const int t = min(tb + ps * RPP + prow, p.T - 1);
+          accv[ps] = *reinterpret_cast<const float4*>(out_b + (long long)t * C + ecol);
         }
       }
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(patch + li * ELD + n * 32 + 8 * q + 4 * lh) =
+              make_float4(acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]);
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = ps * RPP + prow;
+        const int t = tb + row;
+        float4 v = *reinterpret_cast<const float4*>(patch + row * ELD + pc4);
+        v.x += bias2.x; v.y += bias2.y; v.z += bias2.z; v.w += bias2.w;
+        const float4 rv = resv[ps];
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        if constexpr (ACCUM) {
+          const float4 ov = accv[ps];
+          v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
+          if (p.out_div != 1.0f) {
+            v.x = v.x / p.out_div; v.y = v.y / p.out_div; v.z = v.z / p.out_div; v.w = v.w / p.out_div;
+          }
+        }
+        // streaming store: this kernel never reads the tile back, and keeping it out of the way leaves the x rows (slab halo of the
+        // neighbour tile, residual re-read) in L2
+        if (t < t_end && wm * WM + m * 32 + row < BMO) {
+          typedef float f32x4_t __attribute__((ext_vector_type(4)));
+          const f32x4_t nv = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(nv, reinterpret_cast<f32x4_t*>(out_b + (long long)t * C + ecol));
+        }
+      }
+    }
   };
 
   // ---- main
@@ -346,7 +358,7 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
     const bool lastc = c + 1 == NCH;
     run_taps(std::integral_constant<int, 1>{}, smem + (c * irows + wm * WM + li) * LDK + lh * 4, LDK, 1, c, 1, lastc ? 0 : c + 1);
   }
-  __syncthreads();  // intermediate dead: the region now carries the transpose patches
+  __syncthreads();  // intermediate dead: the region now carries the epilogue's patches
   epilogue2(tile);
 }
 

@@ -151,7 +151,7 @@ def pinned(shape, dtype, torch, stub):
 def roofline_of(dom, steps, traffic_json):
     """Roofline record of one kernel class from its HIP-event statistics over `steps` steps."""
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    x3 = dom["name"].startswith(X3_CLASSES)
+    x3 = dom["name"].startswith(X3_CLASSES) and "_f32_" not in dom["name"]   # resblock_pair_f32_*: the fused pair on the fp32 MFMA
     peak = PEAK_BF16_TFLOPS / 3.0 if x3 else PEAK_FP32_TFLOPS
     traffic = traffic_json.get(dom["name"], {}).get("hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -612,7 +612,7 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
 // at 64 and 32 columns, where the weight tile is small next to the slab.
 template <int BM, int BN, int WM, int WN, int MODE>
 const char* launch_cfg(const ConvParams& p, hipStream_t s) {
-  if constexpr (BN == 128) {
+  if constexpr (BN == 128) {  // (fp32 fragments for the 64- / 32-column tiles were measured too: 0 .. -6 %, the LDS tile stays there)
     // plain Linear layers (q | k | v, fc, the k = 1 FFN conv, every Conformer GEMM): several chunks per work item
     static const int cpi_env = getenv("E2ETTS_K1_CPI") ? atoi(getenv("E2ETTS_K1_CPI")) : 4;  // tuning aid: 0 = off, 2, 4
     if constexpr (BM == 128 || BM == 64) {

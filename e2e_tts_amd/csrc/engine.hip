@@ -102,6 +102,9 @@ struct e2etts_engine {
   // stage_fused[i]: every pair of stage i can run fused (channels 32 / 64 / 128)
   std::vector<std::vector<float*>> rb_pair_frag;
   std::vector<float*> rb_frag_base;  // the allocations rb_pair_frag points into (one per ResBlock)
+  // the same for the exact-fp32 mode (launch_f32_to_frag order), built for the stages of <= 64 channels only: wider stages are bound by
+  // the fp32 matrix pipe, where the fused kernel's (KW - 1) / BMI recompute costs more than its saved HBM traffic buys
+  std::vector<std::vector<float*>> rb_pair_frag32;
   std::vector<char> stage_fused;
   int fuse_pairs = 2;  // e2etts_set_fused_resblocks: 0 off, 1 pairs, 2 pairs + whole k = 3 ResBlocks
 
@@ -283,6 +286,7 @@ void free_frags(e2etts_engine* e) {
     if (f) (void)hipFree(f);
   e->rb_frag_base.clear();
   e->rb_pair_frag.clear();
+  e->rb_pair_frag32.clear();
   e->stage_fused.clear();
   e->dev_bytes -= e->frag_bytes;
   e->frag_bytes = 0;
@@ -501,6 +505,7 @@ int bind_vocoder(e2etts_engine* e) {
   e->rb_c1.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
   e->rb_c2.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
   e->rb_pair_frag.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
+  e->rb_pair_frag32.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
   e->stage_fused.clear();
   uint64_t ch = C0;
   for (int i = 0; i < c.voc_stages; ++i) {
@@ -545,6 +550,19 @@ int bind_vocoder(e2etts_engine* e) {
         e->rb_pair_frag[idx].push_back(f);
         KCHK(e, launch_x3_to_frag(e->rb_c1[idx][m].wx3, f, (int)ch, k, (int)ch, e->stream));
         KCHK(e, launch_x3_to_frag(e->rb_c2[idx][m].wx3, f + one / 4, (int)ch, k, (int)ch, e->stream));
+      }
+      if (ch <= 64) {  // fp32 images of the same pairs
+        float* b32 = nullptr;
+        HIPCHK(e, hipMalloc(&b32, 2 * one * c.voc_n_dil));
+        e->dev_bytes += 2 * one * c.voc_n_dil;
+        e->frag_bytes += 2 * one * c.voc_n_dil;
+        e->rb_frag_base.push_back(b32);
+        for (int m = 0; m < c.voc_n_dil; ++m) {
+          float* f = b32 + (size_t)m * 2 * (one / 4);
+          e->rb_pair_frag32[idx].push_back(f);
+          KCHK(e, launch_f32_to_frag(e->rb_c1[idx][m].w, f, (int)ch, k, (int)ch, e->stream));
+          KCHK(e, launch_f32_to_frag(e->rb_c2[idx][m].w, f + one / 4, (int)ch, k, (int)ch, e->stream));
+        }
       }
     }
   }
@@ -985,13 +1003,14 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       const int idx = i * c.voc_n_kernels + j;
       const int k = c.voc_rb_kernel[j];
       const float* cur = XU;
-      bool fused = e->fuse_pairs && e->voc_precision != E2ETTS_PRECISION_FP32 && e->stage_fused[i];
+      const bool f32 = e->voc_precision == E2ETTS_PRECISION_FP32;
+      bool fused = e->fuse_pairs && e->stage_fused[i] && (!f32 || !e->rb_pair_frag32[idx].empty());
       // 256 channels: the fused pair runs ONE 512-thread workgroup per CU on tiles of ~118-126 rows; with fewer tiles than CUs (small
       // batches: 52 tiles at B = 1, T = 768) the two-launch form on 64 x 64 tiles fills the chip better (B = 1: 5.99 vs 6.45 ms per
       // utterance).  Both forms give the same bits, so the choice is invisible in the output.
       if (fused && co == 256 && (long long)B * (n / 128) < 256) fused = false;
       // the whole ResBlock in one launch (resblock_chain.hip) where it exists: kernel size 3 at 32 / 64 channels
-      const bool chained = fused && e->fuse_pairs >= 2 && resblock_chain_supported(co, k, c.voc_rb_dil[j], c.voc_n_dil);
+      const bool chained = fused && !f32 && e->fuse_pairs >= 2 && resblock_chain_supported(co, k, c.voc_rb_dil[j], c.voc_n_dil);
       if (chained) {
         ChainParams q;
         q.x = XU; q.wfrag = e->rb_pair_frag[idx][0]; q.out = S;
@@ -1011,7 +1030,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         // the whole pair in one launch (resblock_pair.hip); x and out must differ, so the running x ping-pongs CUR / T1
         const bool last = m == c.voc_n_dil - 1;
         PairParams q;
-        q.x = cur; q.wfrag = e->rb_pair_frag[idx][m]; q.b1 = e->rb_c1[idx][m].b; q.b2 = e->rb_c2[idx][m].b;
+        q.x = cur; q.wfrag = f32 ? e->rb_pair_frag32[idx][m] : e->rb_pair_frag[idx][m]; q.b1 = e->rb_c1[idx][m].b; q.b2 = e->rb_c2[idx][m].b;
         q.out = last ? S : (cur == CUR ? T1 : CUR);
         q.act_rows = act_stage[i + 1];
         q.B = B; q.T = (int)n; q.C = co; q.KW = k; q.dil = c.voc_rb_dil[j][m];
@@ -1025,7 +1044,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
           static const bool fine = getenv("E2ETTS_PROFILE_FINE") != nullptr;
           char nm[48];
           if (fine) snprintf(nm, sizeof nm, "pair %d k%d d%d r%lld%s", co, k, q.dil, (long long)B * n, q.accumulate ? "+a" : "");
-          else snprintf(nm, sizeof nm, "resblock_pair_%d", co);
+          else snprintf(nm, sizeof nm, f32 ? "resblock_pair_f32_%d" : "resblock_pair_%d", co);
           ProfScope ps(e, nm, resblock_pair_flops(q), resblock_pair_bytes(q));
           KCHK(e, launch_resblock_pair(q, e->stream));
         }

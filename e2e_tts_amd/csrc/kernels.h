@@ -83,7 +83,8 @@ const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, i
 // (resblock_pair.hip): out = c2(lrelu(c1(lrelu(x)) + b1)) + b2 + x, optionally (out_old + that) / out_div.
 struct PairParams {
   const float* x = nullptr;      // [B, T, C] channels-last; also the residual
-  const float* wfrag = nullptr;  // conv1's fragment-order image followed by conv2's (launch_x3_to_frag, C x KW x C each)
+  const float* wfrag = nullptr;  // conv1's fragment-order image followed by conv2's (C x KW x C each): launch_x3_to_frag's order for
+                                 // mode 1 / 2, launch_f32_to_frag's for mode 0
   const float* b1 = nullptr;     // [C]
   const float* b2 = nullptr;     // [C]
   float* out = nullptr;          // [B, T, C], must not alias x
@@ -93,7 +94,7 @@ struct PairParams {
   float slope = 0.1f;            // leaky-ReLU slope of both activations
   int accumulate = 0;            // out = out_old + result
   float out_div = 1.0f;          // then / out_div (needs accumulate)
-  int mode = 1;                  // 1: bf16x3 split precision, 2: plain bf16
+  int mode = 1;                  // 0: exact fp32, 1: bf16x3 split precision, 2: plain bf16
 };
 bool resblock_pair_supported(int C, int KW, int dil);
 const char* launch_resblock_pair(const PairParams& p, hipStream_t s);

@@ -62,8 +62,13 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 template <int BMI, int C, int WM, int WN>
 constexpr int pair_threads() { return 64 * (BMI / WM) * (C / WN); }
 
-template <int BMI, int C, int WM, int WN, bool SPLIT, bool ACCUM>
+// MODE 0: exact fp32 (v_mfma_f32_32x32x2_f32; LDS rows hold 32 fp32 channels; fp32 fragment order of launch_f32_to_frag) -- round 2;
+// MODE 1: bf16x3 split precision; MODE 2: plain bf16 (rows hold 32 bf16 hi | 32 bf16 lo; fragment order of launch_x3_to_frag).
+template <int BMI, int C, int WM, int WN, int MODE, bool ACCUM>
 __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) void resblock_pair_kernel(const PairParams p) {
+  constexpr bool X3 = MODE != 0;
+  constexpr bool SPLIT = MODE == 1;
+  constexpr int KS = X3 ? 2 : 4;               // k-steps per 32-channel chunk: 2 x 16 (bf16 MFMA) or 4 x (4 MFMAs of k = 2) (fp32)
   constexpr int NCH = C / 32;                  // 32-channel chunks (K of both convs, and N tiles of the intermediate)
   constexpr int NWN = C / WN;
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -138,11 +143,15 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
         float4 v = aok[i] ? areg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         v.x = fmaxf(v.x, v.x * p.slope); v.y = fmaxf(v.y, v.y * p.slope);
         v.z = fmaxf(v.z, v.z * p.slope); v.w = fmaxf(v.w, v.w * p.slope);
-        uint2 hi, lo;
-        split4(v, hi, lo);
-        uint2* row = reinterpret_cast<uint2*>(smem + r * LDK);
-        row[lc4 >> 2] = hi;        // 4 bf16 = 8 bytes at bf16 index lc4
-        row[8 + (lc4 >> 2)] = lo;  // lo half starts at byte 64
+        if constexpr (X3) {
+          uint2 hi, lo;
+          split4(v, hi, lo);
+          uint2* row = reinterpret_cast<uint2*>(smem + r * LDK);
+          row[lc4 >> 2] = hi;        // 4 bf16 = 8 bytes at bf16 index lc4
+          row[8 + (lc4 >> 2)] = lo;  // lo half starts at byte 64
+        } else {
+          *reinterpret_cast<float4*>(smem + r * LDK + lc4) = v;
+        }
       }
     }
   };
@@ -152,17 +161,19 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
   // are requested one whole tap ahead into the other of two buffers.  Which buffer a tap reads is a compile-time parity; taps
   // alternate, a run has an odd number of taps, so conv1 starts at parity 0 and conv2 at parity 1.
   constexpr bool DEEP = C == 32;
-  float4 bfr[DEEP ? 2 : 1][2][NT][2];
+  float4 bfr[DEEP ? 2 : 1][KS][NT][SPLIT ? 2 : 1];
   auto load_frag_n = [&](auto par, int conv, int chunk, int j, int ks, int n) {
     constexpr int P = decltype(par)::value;
 #pragma unroll
     for (int hl = 0; hl < (SPLIT ? 2 : 1); ++hl) {
       const int nt = wn * NT + n;
-      const int soff = (conv * frag_words + (((((nt * KW + j) * NCH + chunk) * 2 + ks) * 2 + hl) << 8)) * 4;
+      // 4 KiB per (32-column tile, tap, chunk) in either order: [k-step 0..1][hi | lo] or [q 0..3], 1 KiB each
+      const int piece = X3 ? ks * 2 + hl : ks;
+      const int soff = (conv * frag_words + (((((nt * KW + j) * NCH + chunk) * 4) + piece) << 8)) * 4;
       bfr[P][ks][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
     }
   };
-  auto load_frag = [&](int conv, int chunk, int j, int ks) {
+  auto load_frag = [&](int conv, int chunk, int j, int ks) {  // (prologue only)
 #pragma unroll
     for (int n = 0; n < NT; ++n) load_frag_n(std::integral_constant<int, 0>{}, conv, chunk, j, ks, n);
   };
@@ -172,41 +183,63 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
     constexpr int P = decltype(par)::value;
     if constexpr (DEEP) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int n = 0; n < NT; ++n) load_frag_n(std::integral_constant<int, 1 - P>{}, nconv, nchunk, nj, ks, n);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // TRANSPOSED product D^T = W . X^T: the weight fragment is the A operand (rows = output channels), the activation rows
+    // are B (columns = positions) -- the operand images are the same either way and so are the bits (conv_gemm's order of terms
+    // and k-steps is kept).  An accumulator lane then holds ONE position and, per register quad, four consecutive channels.
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[MT], al[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        ah[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + ks * 8));
-        if constexpr (SPLIT) al[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + 16 + ks * 8));
-      }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
+    for (int ks = 0; ks < KS; ++ks) {
+      if constexpr (X3) {
+        bf16x8 ah[MT], al[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          // TRANSPOSED product D^T = W . X^T: the weight fragment is the A operand (rows = output channels), the activation rows
-          // are B (columns = positions) -- the operand images are the same either way and so are the bits (the terms keep
-          // conv_gemm's order: x_lo w_hi, x_hi w_lo, x_hi w_hi).  An accumulator lane then holds ONE position and, per register
-          // quad, four consecutive channels: both epilogues work on float4 / packed pairs with no transpose through LDS.
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[P][ks][n][0]);
-          if constexpr (SPLIT) {
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[P][ks][n][1]);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[m], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
-          }
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
+          ah[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + ks * 8));
+          if constexpr (SPLIT) al[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + 16 + ks * 8));
         }
-        if constexpr (!DEEP) {
-          // keep the request right behind the MFMAs that free its registers (left alone, hipcc sinks all requests to the end
-          // of the iteration, a few cycles before the next one waits for them)
-          __builtin_amdgcn_sched_barrier(0);
-          load_frag_n(std::integral_constant<int, 0>{}, nconv, nchunk, nj, ks, n);
-          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[P][ks][n][0]);
+            if constexpr (SPLIT) {  // x_lo w_hi, x_hi w_lo, x_hi w_hi
+              const bf16x8 bl = __builtin_bit_cast(bf16x8, bfr[P][ks][n][1]);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
+            }
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
+          }
+          if constexpr (!DEEP) {
+            // keep the request right behind the MFMAs that free its registers (left alone, hipcc sinks all requests to the end
+            // of the iteration, a few cycles before the next one waits for them)
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag_n(std::integral_constant<int, 0>{}, nconv, nchunk, nj, ks, n);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
+        // exact fp32: lane (li, lh) holds k = 8 ks + 4 lh + r of its row for both operands; MFMA r consumes component r
+        float4 af[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + ks * 8);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float4 bf = bfr[P][ks][n][0];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af[m].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af[m].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.z, af[m].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af[m].w, acc[m][n], 0, 0, 0);
+          }
+          if constexpr (!DEEP) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag_n(std::integral_constant<int, 0>{}, nconv, nchunk, nj, ks, n);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
@@ -250,6 +283,10 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
             v[i] = fmaxf(v[i], v[i] * p.slope);
             v[i] = ok ? v[i] : 0.f;
             acc[m][n][4 * q + i] = 0.f;
+          }
+          if constexpr (!X3) {  // fp32 image row: the four channels as they are
+            *reinterpret_cast<float4*>(smem + (chunk * irows + row) * LDK + 8 * q + 4 * lh) = make_float4(v[0], v[1], v[2], v[3]);
+            continue;
           }
           uint2 hi;
           hi.x = pack_bf16(v[0], v[1]);
@@ -335,7 +372,7 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
   load_a(tile, 0);
   store_a();
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) load_frag(0, 0, 0, ks);
+  for (int ks = 0; ks < KS; ++ks) load_frag(0, 0, 0, ks);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing in flight at the loop heads: their waits stay counted (see conv_gemm.hip)
 
   // conv1: K = chunks of x, slab re-staged per chunk
@@ -362,7 +399,7 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
   epilogue2(tile);
 }
 
-template <int BMI, int C, int WM, int WN, bool SPLIT>
+template <int BMI, int C, int WM, int WN, int MODE>
 const char* launch_pair_cfg(const PairParams& p, hipStream_t s) {
   const int halo1 = p.dil * (p.KW - 1);
   const int BMO = BMI - (p.KW - 1);
@@ -373,9 +410,9 @@ const char* launch_pair_cfg(const PairParams& p, hipStream_t s) {
   dim3 grid((mtiles + 7) / 8 * 8, p.B);  // a multiple of 8 (see the XCD-aware order in the kernel); extra blocks exit
   constexpr int NTHR = pair_threads<BMI, C, WM, WN>();
   if (p.accumulate)
-    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, true>), grid, dim3(NTHR), lds, s, p);
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, MODE, true>), grid, dim3(NTHR), lds, s, p);
   else
-    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, SPLIT, false>), grid, dim3(NTHR), lds, s, p);
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, MODE, false>), grid, dim3(NTHR), lds, s, p);
   return hipGetLastError() == hipSuccess ? nullptr : "resblock_pair: launch failed";
 }
 
@@ -384,13 +421,16 @@ const char* launch_pair_mode(const PairParams& p, hipStream_t s) {
   static bool attr_done = false;  // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
   if (!attr_done) {
     const int cap = C == 256 ? (int)PAIR_MAX_LDS : 80 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<BMI, C, WM, WN, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     attr_done = true;
   }
-  return p.mode == 1 ? launch_pair_cfg<BMI, C, WM, WN, true>(p, s) : launch_pair_cfg<BMI, C, WM, WN, false>(p, s);
+  if (p.mode == 0) return launch_pair_cfg<BMI, C, WM, WN, 0>(p, s);
+  return p.mode == 1 ? launch_pair_cfg<BMI, C, WM, WN, 1>(p, s) : launch_pair_cfg<BMI, C, WM, WN, 2>(p, s);
 }
 
 }  // namespace
@@ -411,7 +451,7 @@ const char* launch_resblock_pair(const PairParams& p, hipStream_t s) {
   if (!p.x || !p.wfrag || !p.b1 || !p.b2 || !p.out) return "resblock_pair: null pointer";
   if (p.B <= 0 || p.T <= 0) return "resblock_pair: bad dims";
   if (!resblock_pair_supported(p.C, p.KW, p.dil)) return "resblock_pair: unsupported channels / kernel / dilation";
-  if (p.mode != 1 && p.mode != 2) return "resblock_pair: mode must be 1 (bf16x3) or 2 (bf16)";
+  if (p.mode < 0 || p.mode > 2) return "resblock_pair: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16)";
   if (p.slope < 0.f || p.slope > 1.f) return "resblock_pair: slope must lie in [0, 1]";
   if (p.out_div != 1.0f && !p.accumulate) return "resblock_pair: out_div needs accumulate";
   if ((((uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.wfrag | (uintptr_t)p.b2) & 15) || (p.x_bs & 3) || (p.out_bs & 3))

@@ -28,9 +28,9 @@ def kernel_class(name: str):
     if m:
         bm, bn, mode = m.group(1), m.group(2), int(m.group(3))
         return ("conv_gemm_" if mode == 0 else "conv_x3_") + f"{bm}x{bn}"  # bench.py's classes
-    m = re.search(r"resblock_pair_kernel<\d+, (\d+)", name)
+    m = re.search(r"resblock_pair_kernel<\d+, (\d+), \d+, \d+, (\d+)", name)
     if m:
-        return "resblock_pair_" + m.group(1)
+        return ("resblock_pair_f32_" if m.group(2) == "0" else "resblock_pair_") + m.group(1)
     m = re.search(r"resblock_chain_kernel<\d+, (\d+)", name)
     if m:
         return "resblock_chain_" + m.group(1)

@@ -248,7 +248,10 @@ def main():
         torch.cuda.set_device(local_rank)
     dist = None
     backend = None
-    if world > 1:
+    # E2ETTS_BENCH_FORCE_DIST=1: take the collective branch even with one rank (tests/test_gpu_dropin.py runs it under torchrun on the
+    # one-GPU box, so the RCCL code path -- process group on the device, broadcasts, barrier, MAX all-reduce -- has executed somewhere)
+    force_dist = os.environ.get("E2ETTS_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         backend = "gloo" if (rehearsal or stub) else "nccl"   # "nccl" IS RCCL on ROCm
         if backend == "gloo":
@@ -279,7 +282,7 @@ def main():
     else:
         nbytes = torch.zeros(1, dtype=torch.int64, device=bcast_dev)
     weight_bcast_ms = None
-    if world > 1:
+    if dist is not None:
         dist.broadcast(nbytes, src=0)
         if rank != 0:
             blob = torch.empty(int(nbytes.item()), dtype=torch.uint8, device=bcast_dev)

@@ -551,7 +551,11 @@ int bind_vocoder(e2etts_engine* e) {
         KCHK(e, launch_x3_to_frag(e->rb_c1[idx][m].wx3, f, (int)ch, k, (int)ch, e->stream));
         KCHK(e, launch_x3_to_frag(e->rb_c2[idx][m].wx3, f + one / 4, (int)ch, k, (int)ch, e->stream));
       }
-      if (ch <= 64) {  // fp32 images of the same pairs
+      // at 128 / 256 channels the fp32 kernels are bound by the matrix pipe and the fused form recomputes (KW - 1) / 128 of its rows:
+      // it pays up to a kernel size that the environment can move (tuning aid; same bits either way)
+      static const int f32_k128 = getenv("E2ETTS_F32_FUSE_K128") ? atoi(getenv("E2ETTS_F32_FUSE_K128")) : 7;
+      static const int f32_k256 = getenv("E2ETTS_F32_FUSE_K256") ? atoi(getenv("E2ETTS_F32_FUSE_K256")) : 0;
+      if (ch <= 64 || (ch == 128 && k <= f32_k128) || (ch == 256 && k <= f32_k256)) {  // fp32 images of the same pairs
         float* b32 = nullptr;
         HIPCHK(e, hipMalloc(&b32, 2 * one * c.voc_n_dil));
         e->dev_bytes += 2 * one * c.voc_n_dil;

@@ -249,3 +249,29 @@ def test_load_weights_bcast_over_rccl_single_rank_communicator(tmp_path):
     script.write_text(_BCAST_CHILD)
     r = subprocess.run([sys.executable, str(script), ROOT, os.path.join(GOLD, "tiny_b3.npz")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "BCAST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_collective_branch_runs_on_rccl_single_rank():
+    """bench.py's multi-GPU branch on the REAL collective backend: launched by torch.distributed.run with one rank on this box's GPU and
+    E2ETTS_BENCH_FORCE_DIST=1, so init_process_group("nccl", device_id=...), the size + blob broadcasts, the barriers and the MAX
+    all-reduce execute on RCCL (with N ranks the same calls run unchanged; the N = 2 contract is rehearsed on CPU in
+    tests/test_dist_gloo.py)."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, E2ETTS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["collective_backend"] == "nccl" and d["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    assert d["weight_bcast_ms"] is not None and d["weight_bcast_ms"] >= 0 and d["weight_blob_bytes"] > 100_000_000
+    assert d["dtype"] == "f32" and d["value"] > 22050 * 100

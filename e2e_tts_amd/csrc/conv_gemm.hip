@@ -663,10 +663,10 @@ const char* conv_gemm_class(const ConvParams& p) {
   return p.Cout > 32 ? "conv_gemm_256x64" : "conv_gemm_256x32";
 }
 
-double conv_gemm_flops(const ConvParams& p) { return 2.0 * p.B * (double)p.T * p.Cout * p.KW * p.Cin; }
+double conv_gemm_flops(const ConvParams& p) { return 2.0 * p.B * (double)p.T * p.act_frac * p.Cout * p.KW * p.Cin; }
 
 double conv_gemm_bytes(const ConvParams& p) {
-  double e = (double)p.B * p.T * (p.Cin + p.Cout * (1.0 + (p.res ? 1 : 0) + (p.accumulate ? 1 : 0)));
+  double e = (double)p.B * p.T * p.act_frac * (p.Cin + p.Cout * (1.0 + (p.res ? 1 : 0) + (p.accumulate ? 1 : 0)));
   e += (double)p.Cout * p.KW * p.Cin;
   return 4.0 * e;
 }

@@ -34,6 +34,8 @@ struct ConvParams {
   float act_slope = 0.0f;
   int accumulate = 0;     // out = out_old + value
   float out_div = 1.0f;   // then value / out_div
+  double act_frac = 1.0;  // host-side bookkeeping only: the fraction of the B x T rows that act_rows leaves to compute (ragged
+                          // batches), so that conv_gemm_flops / _bytes count the work really done
 };
 // returns nullptr on success, else a static error string
 const char* launch_conv_gemm(const ConvParams& p, hipStream_t s);
@@ -95,6 +97,7 @@ struct PairParams {
   int accumulate = 0;            // out = out_old + result
   float out_div = 1.0f;          // then / out_div (needs accumulate)
   int mode = 1;                  // 0: exact fp32, 1: bf16x3 split precision, 2: plain bf16
+  double act_frac = 1.0;         // host-side bookkeeping only (see ConvParams::act_frac)
 };
 bool resblock_pair_supported(int C, int KW, int dil);
 const char* launch_resblock_pair(const PairParams& p, hipStream_t s);
@@ -117,6 +120,7 @@ struct ChainParams {
   int accumulate = 0;
   float out_div = 1.0f;
   int mode = 1;                    // 1: bf16x3 split precision, 2: plain bf16
+  double act_frac = 1.0;           // host-side bookkeeping only (see ConvParams::act_frac)
 };
 bool resblock_chain_supported(int C, int KW, const int* dil, int n_dil);
 const char* launch_resblock_chain(const ChainParams& p, hipStream_t s);

@@ -348,10 +348,10 @@ bool resblock_chain_supported(int C, int KW, const int* dil, int n_dil) {
   return true;
 }
 
-double resblock_chain_flops(const ChainParams& p) { return NP * 2.0 * 2.0 * p.B * (double)p.T * p.C * p.KW * p.C; }
+double resblock_chain_flops(const ChainParams& p) { return NP * 2.0 * 2.0 * p.B * (double)p.T * p.act_frac * p.C * p.KW * p.C; }
 
 double resblock_chain_bytes(const ChainParams& p) {
-  return 4.0 * ((double)p.B * p.T * p.C * (2.0 + (p.accumulate ? 1 : 0)) + NP * 2.0 * p.C * p.KW * p.C);
+  return 4.0 * ((double)p.B * p.T * p.act_frac * p.C * (2.0 + (p.accumulate ? 1 : 0)) + NP * 2.0 * p.C * p.KW * p.C);
 }
 
 const char* launch_resblock_chain(const ChainParams& p, hipStream_t s) {

@@ -441,10 +441,10 @@ bool resblock_pair_supported(int C, int KW, int dil) {
   return C != 256 || (size_t)(C / 32) * (128 + KW - 1) * LDK * 4 <= PAIR_MAX_LDS;
 }
 
-double resblock_pair_flops(const PairParams& p) { return 2.0 * 2.0 * p.B * (double)p.T * p.C * p.KW * p.C; }
+double resblock_pair_flops(const PairParams& p) { return 2.0 * 2.0 * p.B * (double)p.T * p.act_frac * p.C * p.KW * p.C; }
 
 double resblock_pair_bytes(const PairParams& p) {
-  return 4.0 * ((double)p.B * p.T * p.C * (2.0 + (p.accumulate ? 1 : 0)) + 2.0 * p.C * p.KW * p.C);
+  return 4.0 * ((double)p.B * p.T * p.act_frac * p.C * (2.0 + (p.accumulate ? 1 : 0)) + 2.0 * p.C * p.KW * p.C);
 }
 
 const char* launch_resblock_pair(const PairParams& p, hipStream_t s) {

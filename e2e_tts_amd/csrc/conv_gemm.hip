@@ -111,7 +111,8 @@ template <int BM, int BN, int MODE, bool BFRAG, int CPI>
 constexpr int conv_min_waves() { return (MODE == 0 && BFRAG && CPI == 0 && BM * BN <= 128 * 128) ? E2ETTS_F32_OCC : 2; }
 
 template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0>
-__global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block) {
+__global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block,
+                                                                                                      const int gx, const int ny) {
   constexpr bool K1 = CPI > 0;
   static_assert(!K1 || BFRAG, "multi-chunk items exist on the fragment path only");
   constexpr bool X3 = MODE != 0;
@@ -137,12 +138,25 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
   const int li = lane & 31, lh = lane >> 5;
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
 
-  const int b = blockIdx.z;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware work mapping (1-D grid).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: linear id L runs on XCD
+  // L % 8 (observed placement: speed only, never correctness).  A unit of work = (row group g = `tiles_per_block` consecutive tiles of one
+  // utterance, column tile y); on each XCD consecutive ids walk the COLUMN TILES of one row group first, so the ny workgroups that read
+  // the same activation slab run on the same L2 at about the same time (with an (x, y, z) grid they were a whole grid row apart, on
+  // whatever XCD that happened to be), and row groups are interleaved over the XCDs, which keeps them evenly loaded when ragged batches
+  // make some utterances short.  PMC: FETCH_SIZE of the decoder's Linear layers (8-9 column tiles) -38 %; speed unchanged (these
+  // kernels wait on the matrix pipe, not on memory).  Tried and not taken: a contiguous eighth of each utterance's row groups per XCD
+  // (so that neighbouring tiles find their halo rows in the same L2): -5 % FETCH_SIZE on the dilated layers, but 4 x the workgroups
+  // for the short sequences of the encoder (+0.45 ms/step).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int by = slot % ny;
+  const int g = (slot / ny) * 8 + xcd;
+  if (g >= gx * p.B) return;  // the padding of the grid to a multiple of 8 row groups
+  const int b = g / gx, bx = g - b * gx;
+  const int n0 = by * BN;
   // ragged batches: rows >= act_rows[b] are not needed by anyone (see engine.hip) -- whole tiles beyond them are skipped
   const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
   const int mtiles = (t_act + BM - 1) / BM;
-  const int tile0 = blockIdx.x * tiles_per_block;
+  const int tile0 = bx * tiles_per_block;
   const int ntile = min(tiles_per_block, mtiles - tile0);
   if (ntile <= 0) return;  // uniform for the workgroup, before any barrier
   const float* in_b = p.in + (long long)b * p.in_bs;
@@ -577,7 +591,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
     }
   }
 #ifdef E2ETTS_DIAG
-  if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+  if (bx == 1 && by == 0 && b == 0 && tid == 0) {
     for (int i = 0; i < 7; ++i) g_conv_diag[i] = dsum[i];
     g_conv_diag[7] = niter;
   }
@@ -603,8 +617,11 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   int tpb = (int)(total / (256 * wg_per_cu));
   tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
   if (tpb > mtiles) tpb = mtiles;
-  dim3 grid((mtiles + tpb - 1) / tpb, ntiles, p.B);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI>), grid, dim3(256), lds, s, p, tpb);
+  const int gx = (mtiles + tpb - 1) / tpb;                        // row groups per utterance
+  const long long groups8 = ((long long)gx * p.B + 7) / 8;        // row groups per XCD
+  if (groups8 * 8 * ntiles >= (1LL << 31)) return "conv_gemm: grid too large";
+  dim3 grid((unsigned)(groups8 * 8 * ntiles));
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI>), grid, dim3(256), lds, s, p, tpb, gx, ntiles);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
 }
 

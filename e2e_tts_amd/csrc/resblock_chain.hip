@@ -356,8 +356,10 @@ double resblock_chain_bytes(const ChainParams& p) {
 
 const char* launch_resblock_chain(const ChainParams& p, hipStream_t s) {
   if (!p.x || !p.wfrag || !p.out) return "resblock_chain: null pointer";
-  for (int m = 0; m < NP; ++m)
+  for (int m = 0; m < NP; ++m) {
     if (!p.b1[m] || !p.b2[m]) return "resblock_chain: null bias";
+    if (((uintptr_t)p.b1[m] | (uintptr_t)p.b2[m]) & 15) return "resblock_chain: bias vectors must be 16-byte aligned (read as float4)";
+  }
   if (p.B <= 0 || p.T <= 0) return "resblock_chain: bad dims";
   if (!resblock_chain_supported(p.C, p.KW, p.dil, NP)) return "resblock_chain: unsupported channels / kernel / dilations";
   if (p.mode != 1 && p.mode != 2) return "resblock_chain: mode must be 1 (bf16x3) or 2 (bf16)";

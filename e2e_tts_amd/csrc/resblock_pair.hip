@@ -454,7 +454,7 @@ const char* launch_resblock_pair(const PairParams& p, hipStream_t s) {
   if (p.mode < 0 || p.mode > 2) return "resblock_pair: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16)";
   if (p.slope < 0.f || p.slope > 1.f) return "resblock_pair: slope must lie in [0, 1]";
   if (p.out_div != 1.0f && !p.accumulate) return "resblock_pair: out_div needs accumulate";
-  if ((((uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.wfrag | (uintptr_t)p.b2) & 15) || (p.x_bs & 3) || (p.out_bs & 3))
+  if ((((uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.wfrag | (uintptr_t)p.b1 | (uintptr_t)p.b2) & 15) || (p.x_bs & 3) || (p.out_bs & 3))
     return "resblock_pair: pointers must be 16-byte aligned";
   if ((long long)p.T * p.C * 4 >= (1LL << 31)) return "resblock_pair: one utterance must stay below 2 GiB (32-bit buffer offsets)";
   if (p.x == p.out) return "resblock_pair: in-place is not possible (tiles read their neighbours' rows)";

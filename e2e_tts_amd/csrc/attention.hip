@@ -21,8 +21,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// Two workgroups per CU (2 waves / SIMD): at DK = 192 the Q fragments (96 registers) and the O accumulators (96) leave little, and with a
+// one-argument __launch_bounds__ hipcc took 380 registers -- ONE wave per SIMD, one workgroup per CU: the 384 workgroups of the decoder
+// (B = 32, T = 768) then ran as a round of 256 and a round of 128 with every staging round trip exposed (0.5 ms per layer).
 template <int DK>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                         const int32_t* __restrict__ lens, int N, int H, float temperature) {
   constexpr int LDS_LD = DK + 4;
   constexpr int DT = DK / 32;  // 32-wide tiles of the head dimension

@@ -703,3 +703,47 @@ def test_full_size_batch_is_deterministic_and_linear_in_batch(blocks):
     half, _, _ = eng.synthesize(np.ascontiguousarray(ids[:5]), lens[:5], spk)
     np.testing.assert_array_equal(half, a[:5])
     assert np.abs(a.astype(np.int32)).max() > 100  # not silence
+
+
+def test_fp32_fragment_path_is_bit_identical_to_the_lds_weight_tile(tmp_path):
+    """conv_gemm's exact-fp32 kernel reads its weights either as MFMA fragments from L2 (default since round 2) or through the LDS
+    weight tile (E2ETTS_NO_FRAG32=1, read once per process): same MFMA order, so the same bits.  The child process runs the default-config
+    B = 3 fixture through the LDS-tile kernels with the fused fp32 pairs switched off as well -- the round-1 path -- and hands back its
+    mel, waveform and PCM; this process runs the default path (fragments + fused fp32 pairs)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import GOLD, ROOT
+    g = load_golden("full_b3")
+    cfg, eng = engine_for(g, "full_b3")
+    eng.set_precision("fp32")
+    eng.set_ragged(False)
+    spk = np.array([int(g["speaker"])], np.int64)
+    d, p, e = (float(x) for x in g["controls"])
+    r = eng.acoustic(g["ids"], g["lens"], spk, d, p, e, want=("mel_lens",))
+    _, mel_post = eng.fetch_mel(r["B"], r["T"], mel=False)
+    wav, pcm = eng.vocoder(None, r["B"], r["T"], pcm=True)
+    eng.set_ragged(True)
+    script = tmp_path / "nofrag_child.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "from conftest import load_golden, states_for\n"
+        "from e2e_tts_amd import config as cfgmod\n"
+        "from e2e_tts_amd.runtime import engine_from_states\n"
+        "g = load_golden('full_b3'); cfg, ac, voc = states_for(g, 'full_b3')\n"
+        "eng = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)\n"
+        "eng.set_precision('fp32'); eng.set_ragged(False); eng.set_fused_resblocks(0)\n"
+        "spk = np.array([int(g['speaker'])], np.int64); d, p, e = (float(x) for x in g['controls'])\n"
+        "r = eng.acoustic(g['ids'], g['lens'], spk, d, p, e, want=('mel_lens',))\n"
+        "_, mel_post = eng.fetch_mel(r['B'], r['T'], mel=False)\n"
+        "wav, pcm = eng.vocoder(None, r['B'], r['T'], pcm=True)\n"
+        "np.savez(sys.argv[1], mel_post=mel_post, wav=wav, pcm=pcm)\n")
+    out = tmp_path / "nofrag.npz"
+    env = dict(os.environ, E2ETTS_NO_FRAG32="1")
+    rr = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=900)
+    assert rr.returncode == 0, rr.stderr[-3000:]
+    o = np.load(out)
+    np.testing.assert_array_equal(o["mel_post"], mel_post)
+    np.testing.assert_array_equal(o["wav"], wav)
+    np.testing.assert_array_equal(o["pcm"], pcm)

@@ -331,7 +331,7 @@ __device__ __forceinline__ void split8(const float* v, bf16x8_t& hi, bf16x8_t& l
 // NW: wavefronts (32 queries each) per workgroup.  Every workgroup of an (utterance, head) pulls ALL its K / V chunks through L2, and that
 // traffic, not arithmetic, is what the staging costs: 8 waves = 256 queries per workgroup halve it against 4.
 template <int DK, int NW>
-__global__ __launch_bounds__(NW * 64) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                            const int32_t* __restrict__ lens, int N, int H, float temperature) {
   constexpr int KS = DK + 4;   // words per K row: DK/2 (hi bf16) + DK/2 (lo bf16) + 4 pad; KS mod 64 == 4 -> conflict-free b128
   constexpr int VS = 36;       // words per Vt row: 16 (32 hi slots) + 16 (32 lo slots) + 4 pad

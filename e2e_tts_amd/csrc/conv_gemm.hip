@@ -629,7 +629,15 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
 // at 64 and 32 columns, where the weight tile is small next to the slab.
 template <int BM, int BN, int WM, int WN, int MODE>
 const char* launch_cfg(const ConvParams& p, hipStream_t s) {
-  if constexpr (BN == 128) {  // (fp32 fragments for the 64- / 32-column tiles were measured too: 0 .. -6 %, the LDS tile stays there)
+  // (fp32 fragments for the 256 x 64 / 256 x 32 tiles were measured too: 0 .. -6 %, the LDS tile stays there.)  The 64 x 64 few-rows tile
+  // -- small batches, the B = 1 latency path, the encoder -- is a chain of short iterations per wave, where the barrier per tap of the
+  // LDS weight tile is a large part of each link: fragments there too (E2ETTS_FRAG64=0: off, tuning aid).
+  static const bool frag64 = !(getenv("E2ETTS_FRAG64") && atoi(getenv("E2ETTS_FRAG64")) == 0);
+  if constexpr (BN == 128 || (BM == 64 && BN == 64)) {
+    if (BN == 64 && !frag64) {
+      return p.accumulate ? launch_cfg_impl<BM, BN, WM, WN, MODE, true, true, false>(p, s)
+                          : launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, false>(p, s);
+    }
     // plain Linear layers (q | k | v, fc, the k = 1 FFN conv, every Conformer GEMM): several chunks per work item
     static const int cpi_env = getenv("E2ETTS_K1_CPI") ? atoi(getenv("E2ETTS_K1_CPI")) : 4;  // tuning aid: 0 = off, 2, 4
     if constexpr (BM == 128 || BM == 64) {

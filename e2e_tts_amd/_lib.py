@@ -77,6 +77,8 @@ def load_library() -> C.CDLL:
     lib.e2etts_vocoder_stream_push.argtypes = [P, P, I, I, C.POINTER(I)]
     lib.e2etts_vocoder_stream_fetch.restype = I
     lib.e2etts_vocoder_stream_fetch.argtypes = [P, P, P, SZ]
+    lib.e2etts_tempo.restype = I
+    lib.e2etts_tempo.argtypes = [P, P, SZ, F, I, P, SZ, C.POINTER(SZ)]
     lib.e2etts_set_precision.restype = I
     lib.e2etts_set_precision.argtypes = [P, I, I]
     lib.e2etts_set_ragged.restype = I
@@ -104,7 +106,7 @@ EXPORTED_SYMBOLS = [
     "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
     "e2etts_fetch_wav", "e2etts_vocoder_stream_begin", "e2etts_vocoder_stream_push", "e2etts_vocoder_stream_fetch",
     "e2etts_set_precision", "e2etts_set_ragged", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_filter", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
-    "e2etts_load_weights_bcast", "e2etts_order_after",
+    "e2etts_load_weights_bcast", "e2etts_order_after", "e2etts_tempo",
 ]
 
 
@@ -340,6 +342,19 @@ class Engine:
         w = np.empty((B, T * self.dims.hop_length), np.float32)
         self._check(self.lib.e2etts_fetch_wav(self._h, _addr(w), w.size), "e2etts_fetch_wav")
         return w
+
+    @_locked
+    def tempo(self, pcm: np.ndarray, speed: float, sample_rate: int = 22050) -> np.ndarray:
+        """Tempo change without pitch change of an int16 signal on the GPU (WSOLA; include/e2etts.h: e2etts_tempo -- parity unpinned,
+        the reference shells out to ffmpeg).  Returns round(len / speed) samples."""
+        pcm = np.ascontiguousarray(pcm)
+        _expect(pcm, "pcm", "int16", pcm.size)
+        n_out = C.c_size_t(0)
+        self._check(self.lib.e2etts_tempo(self._h, _addr(pcm), pcm.size, float(speed), int(sample_rate), None, 0, C.byref(n_out)), "e2etts_tempo")
+        out = np.empty((n_out.value,), np.int16)
+        self._check(self.lib.e2etts_tempo(self._h, _addr(pcm), pcm.size, float(speed), int(sample_rate), _addr(out), out.size, C.byref(n_out)),
+                    "e2etts_tempo")
+        return out
 
     @_locked
     def set_precision(self, vocoder: str = "fp32", decoder: Optional[str] = None):

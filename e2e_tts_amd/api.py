@@ -249,15 +249,21 @@ def time_stretch_wsola(x: np.ndarray, speed: float, sr: int = 22050, frame_ms: f
     return out[: int(round(x.size / speed))]
 
 
-def audio_speed_change(input_path: str, output_path: str = None, speed_rate: float = 1.0) -> str:
+def audio_speed_change(input_path: str, output_path: str = None, speed_rate: float = 1.0, engine: Optional[Engine] = None) -> str:
     """Same signature, output naming and return value as reference API/utils.py:163-172, without the ffmpeg subprocess:
-    reads the WAV, time-stretches it with ``time_stretch_wsola``, writes ``<input>_<speed>.<ext>``."""
+    reads the WAV, time-stretches it and writes ``<input>_<speed>.<ext>``.  With ``engine`` the stretch runs on the GPU
+    (``Engine.tempo`` -> ``e2etts_tempo``, the WSOLA kernel); without one, on the host (``time_stretch_wsola``, the same algorithm in
+    numpy).  Parity unpinned either way: the reference's ffmpeg ``atempo`` filter is not available here."""
     if output_path is None:
         file_type = input_path.split(".")[-1]
         output_path = f"{input_path[:-len(file_type) - 1]}_{round(speed_rate, 2)}.{file_type}"
     audio, sr = read_wav(input_path)
-    y = time_stretch_wsola(audio.astype(np.float64), float(speed_rate), sr)
-    write_wav(output_path, np.clip(np.rint(y), -32768, 32767).astype(np.int16), sr)
+    if engine is not None:
+        pcm = engine.tempo(audio, float(speed_rate), sr)
+    else:
+        y = time_stretch_wsola(audio.astype(np.float64), float(speed_rate), sr)
+        pcm = np.clip(np.rint(y), -32768, 32767).astype(np.int16)
+    write_wav(output_path, pcm, sr)
     return output_path
 
 
@@ -296,5 +302,5 @@ class Synthesizer:
             save_filepath = f"{save_filepath[:-len(file_type) - 1]}_{round(speed, 2)}.{file_type}"
             write_wav(save_filepath, audio, sr)
         if speed != 1 and not in_model:
-            save_filepath = audio_speed_change(save_filepath, speed_rate=speed)
+            save_filepath = audio_speed_change(save_filepath, speed_rate=speed, engine=getattr(self.model, "engine", None))
         return save_filepath

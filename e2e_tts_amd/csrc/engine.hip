@@ -114,6 +114,7 @@ struct e2etts_engine {
   DevBuf logd, durf, cum, mel64, mel32, posbuf, ppred, epred, pidx, eidx;
   DevBuf dx, dxb, mel, melpost, pn1, pn2, encout;
   DevBuf melin, v0, v1, v2, v3, wav, pcm;
+  DevBuf tempo_in, tempo_out;  // e2etts_tempo
   DevBuf istft_q, istft_ri, istft_sp;  // iSTFTNet tail: conv_post output, Re/Im per bin, exp / sin heads (tap "istft_spec_phase")
   int istft_B = 0;
   long long istft_F = 0;
@@ -1516,6 +1517,39 @@ int e2etts_vocoder_stream_fetch(e2etts_engine* e, float* wav_out, int16_t* pcm_o
     HIPCHK(e, hipMemcpy2DAsync(wav_out, ns * 4, ptr<float>(e->wav) + off, src_row * 4, ns * 4, e->st_B, hipMemcpyDefault, e->stream));
   if (pcm_out)
     HIPCHK(e, hipMemcpy2DAsync(pcm_out, ns * 2, ptr<int16_t>(e->pcm) + off, src_row * 2, ns * 2, e->st_B, hipMemcpyDefault, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+int e2etts_tempo(e2etts_engine* e, const int16_t* pcm_in, size_t n_in, float speed, int sample_rate, int16_t* pcm_out, size_t capacity,
+                 size_t* n_out) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!pcm_in || !n_out) return e->fail(E2ETTS_EINVAL, "pcm_in / n_out must not be NULL");
+  if (!(speed >= 0.25f && speed <= 4.0f)) return e->fail(E2ETTS_EINVAL, "speed must lie in [0.25, 4]");
+  if (sample_rate < 4000 || sample_rate > 192000) return e->fail(E2ETTS_EINVAL, "sample_rate out of range");
+  if (n_in == 0 || n_in > (size_t)1 << 30) return e->fail(E2ETTS_EINVAL, "n_in out of range");
+  // the geometry of e2e_tts_amd/api.py: time_stretch_wsola: 40 ms frames (even), 50 % overlap, +-10 ms search
+  const int n = std::max((int)(sample_rate * 40.0 / 1000.0) / 2 * 2, 64);
+  const int hop_out = n / 2, delta = std::max((int)(sample_rate * 10.0 / 1000.0), 1);
+  const double sp = (double)speed;
+  const int n_frames = std::max((int)std::ceil(((double)n_in / sp) / hop_out), 1);
+  const long long want = std::llrint((double)n_in / sp);   // Python round(): half to even
+  const long long avail = (long long)n_frames * hop_out + hop_out;   // what the frames cover; want <= n_frames * hop_out + 1 by the choice of n_frames
+  const long long nout = std::min(want, avail);
+  *n_out = (size_t)nout;
+  if (!pcm_out) return E2ETTS_OK;  // size query
+  if (capacity < (size_t)nout) return e->fail(E2ETTS_EINVAL, "output holds %zu samples, result has %lld", capacity, nout);
+  RET(ensure(e, e->tempo_in, n_in * 2));
+  RET(ensure(e, e->tempo_out, (size_t)std::max<long long>(nout, 1) * 2));
+  RET(copy_in(e, e->tempo_in.p, pcm_in, n_in * 2));
+  if (speed == 1.0f) {
+    RET(copy_out(e, pcm_out, e->tempo_in.p, n_in * 2));
+  } else {
+    KCHK(e, launch_wsola(ptr<int16_t>(e->tempo_in), (long long)n_in, ptr<int16_t>(e->tempo_out), nout, sp, n, delta, n_frames, e->stream));
+    RET(copy_out(e, pcm_out, e->tempo_out.p, (size_t)nout * 2));
+  }
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return E2ETTS_OK;
 }

@@ -149,6 +149,10 @@ const char* launch_dwconv_swish(const float* in, const float* w, const float* bi
 const char* launch_rel_attention(const float* qkv, const float* ps, int ldp, const float* u, float* out, int B, int N, int H, int n_head,
                                  hipStream_t s);
 
+// tempo change without pitch change (WSOLA; small_kernels.hip): x int16 [n_in] -> out int16 [n_out <= n_frames * n / 2 + n / 2]
+const char* launch_wsola(const int16_t* x, long long n_in, int16_t* out, long long n_out, double speed, int n, int delta, int n_frames,
+                         hipStream_t s);
+
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s);
 // wav = tanh(conv7(lrelu_0.01(x))) with Cout = 1; pcm = (int16)(int32)(wav * 32768)
 const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,

@@ -318,6 +318,93 @@ __global__ void f32_to_frag_kernel(const float* __restrict__ w, float4* __restri
   frag[g] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---------------------------------------------------------------- tempo change (WSOLA) for `audio_speed_change`
+// Reference API/utils.py:163-172 shells out to ffmpeg's `atempo` filter (tempo without pitch change).  ffmpeg is not part of this build,
+// so this is waveform-similarity overlap-add (Verhelst & Roelands 1993), the algorithm family behind that filter, restated from the
+// published method -- PARITY UNPINNED against the reference; it mirrors e2e_tts_amd/api.py: time_stretch_wsola step for step (float64).
+// One workgroup walks the output frames of one signal in order (frame i's best offset fixes the template of frame i + 1):
+//   target_i = rint(i hop_in) + delta + n;  best_i = target_i - delta + argmax_lag sum_k seg[lag + k] tmpl[k]  (tmpl = natural continuation
+//   of frame i - 1);  out[i hop_out .. + n) += xp[best_i ..] * hann;   xp = [0 (delta + n) | x | 0 ...].
+__global__ __launch_bounds__(1024) void wsola_kernel(const int16_t* __restrict__ x, long long n_in, int16_t* __restrict__ out, long long n_out,
+                                                     double speed, int n, int delta, int n_frames) {
+  constexpr int NT = 1024;
+  extern __shared__ __attribute__((aligned(16))) double ws_smem[];
+  double* seg = ws_smem;                 // [n + 2 delta]  candidate region around the target
+  double* tmpl = seg + n + 2 * delta;    // [n]            natural continuation of the previous frame
+  double* win = tmpl + n;                // [n]            periodic Hann window, np.hanning(n + 1)[:n]
+  double* open = win + n;                // [n / 2]        the half frame of output that the next frame will still add to
+  double* cval = open + n;               // [NT] reduction scratch
+  int* cidx = reinterpret_cast<int*>(cval + NT);
+  const int tid = threadIdx.x;
+  const int hop_out = n / 2;
+  const double hop_in = hop_out * speed;
+  const long long lead = delta + n;
+  auto xp = [&](long long idx) -> double {
+    const long long j = idx - lead;
+    return (j >= 0 && j < n_in) ? (double)x[j] : 0.0;
+  };
+  auto emit = [&](long long o, double v) {   // out = clip(rint(sum)) as int16 (api.py: audio_speed_change)
+    if (o < n_out) {
+      v = rint(v);
+      v = v < -32768.0 ? -32768.0 : (v > 32767.0 ? 32767.0 : v);
+      out[o] = (int16_t)v;
+    }
+  };
+  for (int k = tid; k < n; k += NT) {
+    win[k] = 0.5 - 0.5 * cos(6.283185307179586476925286766559 * (double)k / (double)n);
+    if (k < hop_out) open[k] = 0.0;
+  }
+  __syncthreads();
+  long long pos = lead;
+  for (int i = 0; i < n_frames; ++i) {
+    const long long target = llrint((double)i * hop_in) + lead;   // round-half-even, as Python's round()
+    long long best = target;
+    if (i > 0) {
+      const long long lo = target - delta;
+      for (int k = tid; k < n + 2 * delta; k += NT) seg[k] = xp(lo + k);
+      for (int k = tid; k < n; k += NT) tmpl[k] = xp(pos + k);
+      __syncthreads();
+      double bv = -1.0e300;
+      int bi = 0x7fffffff;
+      for (int lag = tid; lag <= 2 * delta; lag += NT) {
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;   // four chains: the fp64 FMA latency, not its rate, bounds a single one
+        int k = 0;
+        for (; k + 3 < n; k += 4) {
+          c0 += seg[lag + k] * tmpl[k];
+          c1 += seg[lag + k + 1] * tmpl[k + 1];
+          c2 += seg[lag + k + 2] * tmpl[k + 2];
+          c3 += seg[lag + k + 3] * tmpl[k + 3];
+        }
+        for (; k < n; ++k) c0 += seg[lag + k] * tmpl[k];
+        const double c = (c0 + c1) + (c2 + c3);
+        if (c > bv) { bv = c; bi = lag; }   // lags visited in increasing order: the first maximum of this thread's lags
+      }
+      cval[tid] = bv;
+      cidx[tid] = bi;
+      __syncthreads();
+      for (int st = NT / 2; st > 0; st >>= 1) {
+        if (tid < st) {
+          const double ov = cval[tid + st];
+          const int oi = cidx[tid + st];
+          if (ov > cval[tid] || (ov == cval[tid] && oi < cidx[tid])) { cval[tid] = ov; cidx[tid] = oi; }   // np.argmax: first maximum
+        }
+        __syncthreads();
+      }
+      best = lo + cidx[0];
+      __syncthreads();  // cidx[0] read by everyone before the next frame overwrites it
+    }
+    // out[i hop_out .. + n) += xp[best ..] * win: with 50 % overlap the first half is final now (previous frame's second half + this
+    // frame's first), the second half waits for frame i + 1
+    for (int k = tid; k < hop_out; k += NT) {
+      emit((long long)i * hop_out + k, open[k] + xp(best + k) * win[k]);
+      open[k] = xp(best + k + hop_out) * win[k + hop_out];
+    }
+    __syncthreads();
+    pos = best + hop_out;
+  }
+  for (int k = tid; k < hop_out; k += NT) emit((long long)n_frames * hop_out + k, open[k]);   // the tail of the last frame
+}
+
 // ---- iSTFTNet tail (reference V/generator.py:107-113 + src/tools/stft.py:138-148)
 // x = leaky_relu(x, 0.01); x = ReflectionPad1d((1, 0))(x): frame 0 of the padded signal is frame 1 of the input.
 __global__ void reflect_lrelu_kernel(const float4* __restrict__ in, float4* __restrict__ out, long long n, int c4, float slope) {
@@ -594,6 +681,21 @@ const char* launch_f32_to_frag(const float* w, float* frag, int Cout, int KW, in
   hipLaunchKernelGGL(f32_to_frag_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<float4*>(frag), Cout, KW,
                      Cin, nchunk, groups);
   return CHECK_LAUNCH("f32_to_frag");
+}
+
+const char* launch_wsola(const int16_t* x, long long n_in, int16_t* out, long long n_out, double speed, int n, int delta, int n_frames,
+                         hipStream_t s) {
+  if (!x || !out) return "wsola: null pointer";
+  if (n_in <= 0 || n_out <= 0 || n < 64 || (n & 1) || delta < 1 || n_frames < 1 || !(speed >= 0.25 && speed <= 4.0)) return "wsola: bad arguments";
+  const size_t lds = ((size_t)(n + 2 * delta) + 3 * (size_t)n + 1024) * sizeof(double) + 1024 * sizeof(int);
+  if (lds > 160 * 1024) return "wsola: frame too long for LDS";
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wsola_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wsola_kernel, dim3(1), dim3(1024), lds, s, x, n_in, out, n_out, speed, n, delta, n_frames);
+  return CHECK_LAUNCH("wsola");
 }
 
 const char* launch_reflect_lrelu(const float* in, float* out, int B, long long n, int C, float slope, hipStream_t s) {

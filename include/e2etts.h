@@ -160,6 +160,15 @@ int e2etts_vocoder_stream_begin(e2etts_engine* engine, int B);
 int e2etts_vocoder_stream_push(e2etts_engine* engine, const float* mel_btc, int n_frames, int last, int* n_frames_out);
 int e2etts_vocoder_stream_fetch(e2etts_engine* engine, float* wav_out, int16_t* pcm_out, size_t capacity);
 
+/* Replaces: audio_speed_change (API/utils.py:163-172), which shells out to ffmpeg's `atempo` filter: tempo change without pitch change
+ * of an int16 PCM signal (host or device memory), on the GPU.  ffmpeg is not part of this build: the kernel is waveform-similarity
+ * overlap-add (WSOLA), the algorithm family behind that filter, restated from the published method -- PARITY UNPINNED against the
+ * reference; it mirrors e2e_tts_amd/api.py: time_stretch_wsola (40 ms frames, 50 % overlap, +-10 ms search, float64) step for step.
+ * n_out receives round(n_in / speed); with pcm_out == NULL the call only reports that size.  speed in [0.25, 4].  (The Python mirror's
+ * DEFAULT for speed != 1 is the model's own duration control -- no post-processing at all; this entry serves speed_mode="wsola".) */
+int e2etts_tempo(e2etts_engine* engine, const int16_t* pcm_in, size_t n_in, float speed, int sample_rate, int16_t* pcm_out,
+                 size_t capacity, size_t* n_out);
+
 /* Arithmetic of the convolutions / projections of (a) the vocoder and (b) the decoder + mel_linear + postnet.
  * The encoder and the variance adaptor are always exact fp32: the duration / pitch / energy decisions taken there
  * must be bit-exact, and nothing downstream of the length regulator is discrete.

@@ -275,3 +275,33 @@ def test_bench_collective_branch_runs_on_rccl_single_rank():
     assert d["collective_backend"] == "nccl" and d["rccl_ranks"] == 1 and d["n_gpus"] == 1
     assert d["weight_bcast_ms"] is not None and d["weight_bcast_ms"] >= 0 and d["weight_blob_bytes"] > 100_000_000
     assert d["dtype"] == "f32" and d["value"] > 22050 * 100
+
+
+def test_gpu_tempo_kernel_follows_the_host_wsola():
+    """e2etts_tempo (the WSOLA kernel behind speed_mode="wsola") against e2e_tts_amd.api.time_stretch_wsola, the same algorithm in numpy
+    float64: same length, the same signal up to the rare frame where a near-tie of the cross-correlation resolves differently (the two
+    sum in different orders).  PARITY UNPINNED against the reference, which shells out to ffmpeg's atempo (API/utils.py:163-172)."""
+    from e2e_tts_amd.api import time_stretch_wsola
+    from e2e_tts_amd.runtime import engine_from_states
+    g = load_golden("tiny_b3")
+    cfg, ac, voc = states_for(g, "tiny_b3")
+    eng = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)
+    sr = 22050
+    t = np.arange(int(2.3 * sr)) / sr
+    rng = np.random.Generator(np.random.PCG64(3))
+    x = (6000.0 * np.sin(2 * np.pi * 220.0 * t) * (1 + 0.3 * np.sin(2 * np.pi * 3 * t)) + 1500.0 * np.sin(2 * np.pi * 1730.0 * t)
+         + 200.0 * rng.standard_normal(t.size)).astype(np.int16)
+    np.testing.assert_array_equal(eng.tempo(x, 1.0, sr), x)
+    for speed in (0.5, 0.8, 1.25, 2.0):
+        got = eng.tempo(x, speed, sr)
+        ref = np.clip(np.rint(time_stretch_wsola(x.astype(np.float64), speed, sr)), -32768, 32767).astype(np.int16)
+        assert got.shape == ref.shape == (round(x.size / speed),)
+        same = np.abs(got.astype(np.int32) - ref.astype(np.int32)) <= 1
+        assert same.mean() >= 0.98, (speed, same.mean())
+        spec = np.abs(np.fft.rfft(got.astype(np.float64) * np.hanning(got.size)))
+        assert abs(np.fft.rfftfreq(got.size, 1 / sr)[int(np.argmax(spec))] - 220.0) < 2.0   # pitch stays
+    with pytest.raises(ValueError):
+        eng.tempo(x, 8.0, sr)
+    with pytest.raises(TypeError):
+        eng.tempo(x.astype(np.float32), 1.5, sr)
+    eng.close()

@@ -747,3 +747,37 @@ def test_fp32_fragment_path_is_bit_identical_to_the_lds_weight_tile(tmp_path):
     np.testing.assert_array_equal(o["mel_post"], mel_post)
     np.testing.assert_array_equal(o["wav"], wav)
     np.testing.assert_array_equal(o["pcm"], pcm)
+
+
+def test_fused_kernels_on_unusual_resblock_geometry():
+    """The fused ResBlock kernels take kernel sizes and dilations from the config (reference V/generator.py:27-31, V/layers.py:11-31), not
+    the V1 constants: a generator with kernel sizes (3, 5, 9), dilations (1, 2, 4) / (2, 6, 3) / (1, 1, 1) and stages of 64 / 32 / 16 / 8
+    channels -- the k = 3 ResBlock runs as a chain at 64 and 32 channels with halo 2 + 3 + 5, the others as pairs -- against the numpy
+    oracle (tolerance) and across the fusion levels (bit for bit), on a length that is no multiple of any tile."""
+    from e2e_tts_amd import synth_weights as sw
+    from e2e_tts_amd.models import HifiGan
+    from oracle import ref_numpy as orc
+    cfg = cfgmod.default_config()
+    cfg["models"]["hifigan"].update(upsample_initial_channel=128, resblock_kernel_sizes=[3, 5, 9],
+                                    resblock_dilation_sizes=[[1, 2, 4], [2, 6, 3], [1, 1, 1]])
+    voc = sw.make_vocoder_state(cfg, seed=77)
+    v = HifiGan(cfg["models"]["hifigan"])
+    v.load_state_dict(sw.to_torch(voc))
+    eng = v.eval().to(0).engine
+    rng = np.random.Generator(np.random.PCG64(78))
+    B, T = 3, 37
+    mel = rng.standard_normal((B, T, 80)).astype(np.float32)
+    ref = orc.VocoderOracle(voc, cfg).forward(mel.transpose(0, 2, 1))[:, 0]
+    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 2e-3)):
+        eng.set_precision(prec)
+        outs = []
+        for level in (0, 1, 2):
+            eng.set_fused_resblocks(level)
+            wav, pcm = eng.vocoder(mel, B, T, channels_first=False, pcm=True)
+            outs.append((wav, pcm))
+        assert mean_l1(outs[2][0], ref) < bar, (prec, mean_l1(outs[2][0], ref))
+        for level in (1, 2):
+            np.testing.assert_array_equal(outs[level][0], outs[0][0])
+            np.testing.assert_array_equal(outs[level][1], outs[0][1])
+    eng.set_fused_resblocks(True)
+    eng.close()

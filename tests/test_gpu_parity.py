@@ -781,3 +781,24 @@ def test_fused_kernels_on_unusual_resblock_geometry():
             np.testing.assert_array_equal(outs[level][1], outs[0][1])
     eng.set_fused_resblocks(True)
     eng.close()
+
+
+def test_runaway_durations_are_rejected_not_wrapped():
+    """exp(log_d) that is huge or infinite must not wrap the int32 repeat counts / the frame total into a small T that passes the
+    size checks.  The duration kernel caps a phoneme at 2^20 frames and sums in 64 bits, so the host sees the real magnitude and refuses."""
+    from e2e_tts_amd import synth_weights as sw
+    from e2e_tts_amd.runtime import engine_from_states
+    cfg = cfgmod.tiny_config()
+    stats = cfgmod.DEFAULT_STATS
+    ids = np.random.Generator(np.random.PCG64(5)).integers(4, 131, size=(2, 9)).astype(np.int64)
+    lens = np.array([9, 4], np.int64)
+    spk = np.array([1], np.int64)
+    for bias in (np.log(3.0e6), 60.0, 100.0):   # 3e6 frames per phoneme; 1e26; exp() = inf in fp32
+        ac = sw.make_acoustic_state(cfg, stats, 4, seed=3, mode="fixed")
+        ac["variance_adaptor.duration_predictor.linear.bias"] = np.array([bias], np.float32)
+        eng = engine_from_states(cfg, stats, ac, sw.make_vocoder_state(cfg, seed=4), device=0)
+        with pytest.raises(ValueError, match="exceeds|unreasonably large"):
+            eng.acoustic(ids, lens, spk)
+        with pytest.raises(ValueError, match="exceeds|unreasonably large"):
+            eng.synthesize(ids, lens, spk)
+        eng.close()

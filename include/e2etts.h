@@ -173,7 +173,7 @@ int e2etts_tempo(e2etts_engine* engine, const int16_t* pcm_in, size_t n_in, floa
  * The encoder and the variance adaptor are always exact fp32: the duration / pitch / energy decisions taken there
  * must be bit-exact, and nothing downstream of the length regulator is discrete.
  * E2ETTS_PRECISION_FP32 (default -- the reference's arithmetic): v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain.
- * E2ETTS_PRECISION_BF16X3 (opt-in fast mode, 2.7 x the throughput): every fp32 operand is split into bf16 hi + lo and the
+ * E2ETTS_PRECISION_BF16X3 (opt-in fast mode, 2.6 x the throughput): every fp32 operand is split into bf16 hi + lo and the
  * product keeps hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation -- ~16 significant bits per operand;
  * measured against the reference's own outputs (bench.py `split_precision_mode`): wav mean-L1 1.1e-6 .. 1.3e-6 (fp32: 1.3e-7;
  * plain bf16: 5e-4; parity bar: 1e-4), int16 PCM within 1 LSB on 100 % of samples, discrete outputs untouched. */

@@ -307,9 +307,9 @@ int make_frag(e2etts_engine* e, const float* wx3, uint64_t cout, uint64_t kw, ui
 }
 
 // fp32 weights of a layer the 128-column kernels serve (Cout > 64) -> fp32 fragment order, for the exact-fp32 mode
-int make_frag32(e2etts_engine* e, const float* w, uint64_t cout, uint64_t kw, uint64_t cin) {
+int make_frag32(e2etts_engine* e, const float* w, uint64_t cout, uint64_t kw, uint64_t cin, bool narrow = false) {
   static const bool off = getenv("E2ETTS_NO_FRAG32") != nullptr;  // tuning aid: A/B against the LDS weight tile
-  if (off || !w || cout <= 64 || e->frag_of.count(w)) return E2ETTS_OK;
+  if (off || !w || (cout <= 64 && !narrow) || e->frag_of.count(w)) return E2ETTS_OK;
   float* f = nullptr;
   const size_t bytes = x3_frag_bytes((int)cout, (int)kw, (int)cin);
   HIPCHK(e, hipMalloc(&f, bytes));
@@ -513,6 +513,8 @@ int bind_vocoder(e2etts_engine* e) {
   for (int i = 0; i < c.voc_stages; ++i) {
     const uint64_t cin = ch, cout = ch / 2, s = c.voc_up_rate[i];
     RET(bind_conv(e, "voc.up." + std::to_string(i), s * cout, 3, cin, e->voc_up[i]));
+    // the last upsampler of HiFi-GAN V1 (64 columns), exact fp32: fragments for the zero-tap-skipping 256 x 32 tile (conv_gemm.hip)
+    if (s * cout == 64) RET(make_frag32(e, e->voc_up[i].w, s * cout, 3, cin, true));
     ch = cout;
     for (int j = 0; j < c.voc_n_kernels; ++j) {
       const int idx = i * c.voc_n_kernels + j;

@@ -1238,6 +1238,7 @@ int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
 
 // RCCL entry points, resolved at the first call: from the process image when the host already links or has loaded RCCL (the
 // communicator handed in must come from THAT copy), else from librccl.so.1 (or the file named by E2ETTS_RCCL_LIB).
+extern "C++" {
 namespace {
 typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int, void* /*ncclComm_t*/, hipStream_t);
 typedef int (*nccl_rank_fn)(void*, int*);
@@ -1270,6 +1271,7 @@ RcclApi& rccl_api() {
   return api;
 }
 }  // namespace
+}  // extern "C++"
 
 int e2etts_load_weights_bcast(e2etts_engine* e, const void* blob_or_null, size_t nbytes, void* rccl_comm, int root) {
   if (!e) return E2ETTS_EINVAL;

@@ -22,6 +22,11 @@
 // both operands, so the k order inside an 8-wide group is permuted identically for A and B.
 // Epilogue: accumulators are transposed through a wave-private LDS patch (carved from the idle slab) so that
 // bias / residual / accumulate reads and the result store are float4, 256 B contiguous per 16 lanes.
+//
+// Weights reach the MFMA through that LDS tile (256 x 64 and 256 x 32 tiles) or -- BFRAG: the 128-column tiles and the 64 x 64 few-rows
+// tile, in every arithmetic mode since round 2 -- as MFMA fragments straight from L2, in an order written once at load time
+// (launch_x3_to_frag / launch_f32_to_frag): no LDS weight tile, no barrier per tap.  The grid is one-dimensional and XCD-aware: the
+// column tiles of a row group run next to each other on one XCD's L2 (see the kernel's prologue).
 #include <cstdlib>
 
 #include "host_logic.h"

@@ -40,7 +40,7 @@ def test_48k_vocoder_matches_oracle_in_all_precisions():
     ref = orc.VocoderOracle(voc, cfg).forward(mel.transpose(0, 2, 1))[:, 0]
     assert ref.shape == (2, 90 * 512)
     errs = {}
-    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 1e-3)):   # plain bf16: see test_48k_vocoder_matches_reference_fixture
+    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 6e-4)):   # plain bf16: see test_48k_vocoder_matches_reference_fixture
         eng.set_precision(prec)
         wav, _ = eng.vocoder(mel, 2, 90, channels_first=False)
         errs[prec] = mean_l1(wav, ref)
@@ -54,9 +54,9 @@ def test_48k_vocoder_matches_reference_fixture(tag):
     """The 48 kHz generator against the reference's own HifiGan class (fixture hifigan_48k; V/generator.py:14-53 instantiated with
     upsample_rates [8, 8, 4, 2] / kernels [16, 16, 8, 4]) at widths 64 and 512.  fp32 and split precision meet the fp32 bar.  Plain
     bf16 -- config 5's arithmetic -- rounds every operand to 8 significant bits (relative 2^-9 per product term); SURVEY.md 6 measured
-    torch's bf16 vocoder at wav mean-L1 1.2e-4 against fp32 on trained-scale weights, and the random-init generators here, whose
-    activations are not normalised by training, sit a few times higher: the stated bar is 1e-3 mean-L1 (|wav| mean is 5e-2..7e-2,
-    so that is <= 2 % of the signal), and the measured value is printed."""
+    torch's bf16 vocoder at wav mean-L1 1.2e-4 against fp32, and the random-init generators here measure 3.3e-4 (width 64) and 4.0e-4
+    (width 512) against the reference's fp32 output (fp32: 4e-8 / 9e-8, bf16x3: 6e-7 / 8e-7): the stated bar is 6e-4 mean-L1 = 1.5 x the
+    measured value (|wav| mean is 5e-2..7e-2, so that is ~1 % of the signal); the measured value is printed."""
     from conftest import load_golden
     g = load_golden("hifigan_48k")
     cfg = cfg48(int(g[f"{tag}.width"]))
@@ -64,7 +64,7 @@ def test_48k_vocoder_matches_reference_fixture(tag):
     mel, ref = g[f"{tag}.mel"], g[f"{tag}.wav"]
     B, T = mel.shape[0], mel.shape[1]
     errs = {}
-    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 1e-3)):
+    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 6e-4)):
         eng.set_precision(prec)
         wav, pcm = eng.vocoder(mel, B, T, channels_first=False, pcm=True)
         errs[prec] = mean_l1(wav, ref)
@@ -126,4 +126,4 @@ def test_long_form_60s_stream_bf16():
     exact, _ = eng.vocoder(mel, 1, T, channels_first=False)
     err = mean_l1(out, exact)
     print(f"long-form bf16 vs bf16x3: mean-L1 {err:.3e}")
-    assert err < 1e-3   # the stated plain-bf16 bar (test_48k_vocoder_matches_reference_fixture)
+    assert err < 6e-4   # the stated plain-bf16 bar (test_48k_vocoder_matches_reference_fixture); measured 3.2e-4

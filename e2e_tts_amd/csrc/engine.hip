@@ -257,7 +257,9 @@ int prof_collect(e2etts_engine* e) {
 
 // One conv / linear launch.  alg_scale < 1 when part of the packed weight is structural zeros
 // (the polyphase upsampler) so that the recorded FLOPs stay the algorithmic ones.
-int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
+// ksplit: a phoneme-level layer (encoder FFT blocks, predictors): served by conv_ksplit.hip at every batch size when its fp32 fragment
+// image exists (E2ETTS_KSPLIT=0 routes them through conv_gemm again: tuning aid, changes the summation order of those layers)
+int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0, bool ksplit = false) {
   if (p.in_ld == 0) p.in_ld = p.Cin;
   if (p.out_ld == 0) p.out_ld = p.Cout;
   if (p.res && p.res_ld == 0) p.res_ld = p.Cout;
@@ -274,6 +276,15 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0) {
   if (fine && e->prof_on)
     snprintf(fname, sizeof fname, "%s %d>%d k%d d%d r%lld%s%s", p.x3 ? "x3" : "f32", p.Cin, p.Cout, p.KW, p.dil,
              (long long)p.B * p.T, p.res ? "+r" : "", p.accumulate ? "+a" : "");
+  static const bool ksplit_on = !(getenv("E2ETTS_KSPLIT") && atoi(getenv("E2ETTS_KSPLIT")) == 0);
+  // ... and only where the chain is long (K = KW x Cin >= 768: the FFN convolutions, the predictors): a q | k | v or fc projection
+  // (K = 384) is a chain of 12 short links, and at B = 32 the split costs those more (three idle waves per epilogue) than it saves.
+  // The choice is by layer shape, never by batch size, so every batch size sums every layer in the same order.
+  if (ksplit && ksplit_on && (long long)((p.Cin + 31) / 32) * p.KW >= 24 && conv_ksplit_supported(p)) {
+    ProfScope ps(e, fine && e->prof_on ? fname : "conv_ksplit", conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
+    KCHK(e, launch_conv_ksplit(p, e->stream));
+    return E2ETTS_OK;
+  }
   ProfScope ps(e, fine && e->prof_on ? fname : conv_gemm_class(p), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
   KCHK(e, launch_conv_gemm(p, e->stream));
   return E2ETTS_OK;
@@ -306,10 +317,11 @@ int make_frag(e2etts_engine* e, const float* wx3, uint64_t cout, uint64_t kw, ui
   return E2ETTS_OK;
 }
 
-// fp32 weights of a layer the 128-column kernels serve (Cout > 64) -> fp32 fragment order, for the exact-fp32 mode
-int make_frag32(e2etts_engine* e, const float* w, uint64_t cout, uint64_t kw, uint64_t cin, bool narrow = false) {
+// fp32 weights of a layer the 128-column kernels serve (Cout > 64) -> fp32 fragment order, for the exact-fp32 mode.
+// phoneme_level: a layer conv_ksplit.hip serves -- that kernel has no other weight format, so its image is made whatever the tuning aid says.
+int make_frag32(e2etts_engine* e, const float* w, uint64_t cout, uint64_t kw, uint64_t cin, bool narrow = false, bool phoneme_level = false) {
   static const bool off = getenv("E2ETTS_NO_FRAG32") != nullptr;  // tuning aid: A/B against the LDS weight tile
-  if (off || !w || (cout <= 64 && !narrow) || e->frag_of.count(w)) return E2ETTS_OK;
+  if ((off && !phoneme_level) || !w || (cout <= 64 && !narrow && !phoneme_level) || e->frag_of.count(w)) return E2ETTS_OK;
   float* f = nullptr;
   const size_t bytes = x3_frag_bytes((int)cout, (int)kw, (int)cin);
   HIPCHK(e, hipMalloc(&f, bytes));
@@ -349,10 +361,11 @@ int bind_fft(e2etts_engine* e, const char* side, int layers, std::vector<FFTLaye
     RET(get_tensor(e, p + "b2", H, &f.b2));
     RET(get_tensor(e, p + "ln2.g", H, &f.ln2g));
     RET(get_tensor(e, p + "ln2.b", H, &f.ln2b));
+    const bool ph = side[0] == 'e';  // the encoder runs over phonemes
     RET(make_frag32(e, f.wqkv, 3 * H, 1, H));
     RET(make_frag32(e, f.wo, H, 1, H));
-    RET(make_frag32(e, f.w1, F, c.ffn_k1, H));
-    RET(make_frag32(e, f.w2, H, 1, F));
+    RET(make_frag32(e, f.w1, F, c.ffn_k1, H, false, ph));
+    RET(make_frag32(e, f.w2, H, 1, F, false, ph));
     const uint64_t Hc = (H + 31) / 32 * 32, Fc = (F + 31) / 32 * 32;
     if (e->tensors.count(p + "wqkv.x3")) {
       RET(get_tensor(e, p + "wqkv.x3", 3 * H * Hc, &f.wqkv_x3));
@@ -429,7 +442,7 @@ int bind_pred(e2etts_engine* e, const char* name, int layers, int kernel, int ch
     std::string p = std::string(name) + "." + std::to_string(i) + ".";
     const uint64_t cin = i == 0 ? H : (uint64_t)chans;
     RET(get_tensor(e, p + "w", (uint64_t)chans * kernel * cin, &pr.layers[i].w));
-    RET(make_frag32(e, pr.layers[i].w, chans, kernel, cin));
+    RET(make_frag32(e, pr.layers[i].w, chans, kernel, cin, false, true));
     RET(get_tensor(e, p + "b", chans, &pr.layers[i].b));
     RET(get_tensor(e, p + "g", chans, &pr.layers[i].g));
     RET(get_tensor(e, p + "beta", chans, &pr.layers[i].beta));
@@ -586,7 +599,7 @@ int bind_vocoder(e2etts_engine* e) {
 
 // 6 x FFTBlock (reference U/blocks/transformer.py:178-189), in place on x ([B, N, H]); lens32: device [B]
 int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3,
-              const int32_t* act = nullptr, double act_frac = 1.0) {
+              const int32_t* act = nullptr, double act_frac = 1.0, bool ksplit = false) {
   const auto& c = e->cfg;
   const int H = c.hidden, F = c.ffn_dim;
   float* qkv = ptr<float>(e->qkv);
@@ -599,7 +612,7 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     // q | k | v projections as one GEMM (U/blocks/transformer.py:220-222)
     const bool sx = x3 && f.wqkv_x3;
     p.in = x; p.w = sx ? f.wqkv_x3 : f.wqkv; p.x3 = sx; p.bias = f.bqkv; p.out = qkv; p.Cin = H; p.Cout = 3 * H;
-    RET(conv(e, p));
+    RET(conv(e, p, 1.0, ksplit));
     {
       const double fl = 4.0 * B * c.n_head * (double)N * N * (H / c.n_head);
       ProfScope ps(e, sx ? "attention_x3" : "attention", fl, 4.0 * 4.0 * B * N * H);
@@ -608,7 +621,7 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     // fc + residual (:238-239), LayerNorm eps 1e-5, masked_fill (:182-183)
     p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_frac = act_frac;
     p.in = att; p.w = sx ? f.wo_x3 : f.wo; p.x3 = sx; p.bias = f.bo; p.res = x; p.out = tmp; p.Cin = H; p.Cout = H;
-    RET(conv(e, p));
+    RET(conv(e, p, 1.0, ksplit));
     {
       ProfScope ps(e, "layernorm", 0, 8.0 * B * N * H);
       KCHK(e, launch_layernorm(tmp, xalt, f.ln1g, f.ln1b, lens, B, N, H, 1e-5f, e->stream));
@@ -617,10 +630,10 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_frac = act_frac;
     p.in = xalt; p.w = sx ? f.w1_x3 : f.w1; p.x3 = sx; p.bias = f.b1; p.out = hid; p.Cin = H; p.Cout = F; p.KW = c.ffn_k1; p.pad = (c.ffn_k1 - 1) / 2;
     p.act = ACT_RELU;
-    RET(conv(e, p));
+    RET(conv(e, p, 1.0, ksplit));
     p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_frac = act_frac;
     p.in = hid; p.w = sx ? f.w2_x3 : f.w2; p.x3 = sx; p.bias = f.b2; p.res = xalt; p.out = tmp; p.Cin = F; p.Cout = H;
-    RET(conv(e, p));
+    RET(conv(e, p, 1.0, ksplit));
     {
       ProfScope ps(e, "layernorm", 0, 8.0 * B * N * H);
       KCHK(e, launch_layernorm(tmp, x, f.ln2g, f.ln2b, lens, B, N, H, 1e-5f, e->stream));
@@ -718,7 +731,7 @@ int predictor(e2etts_engine* e, const Predictor& pr, const float* x, float* out,
     ConvParams p;
     p.B = B; p.T = L; p.in = in; p.w = l.w; p.bias = l.b; p.out = a; p.Cin = cin; p.Cout = pr.chans;
     p.KW = pr.kernel; p.pad = (pr.kernel - 1) / 2; p.act = ACT_RELU;
-    RET(conv(e, p));
+    RET(conv(e, p, 1.0, true));  // phoneme-level layer: conv_ksplit.hip at every batch size
     {
       ProfScope ps(e, "layernorm", 0, 8.0 * B * L * pr.chans);
       KCHK(e, launch_layernorm(a, b, l.g, l.beta, mask_lens, B, L, pr.chans, 1e-12f, e->stream));
@@ -828,7 +841,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     KCHK(e, launch_embed(ptr<int64_t>(e->ids), e->emb, pos, x, B, L, H, c.n_symbols + 1, e->stream));
   }
   if (c.block_type == 1) RET(conformer_stack(e, e->cf_enc, x, ptr<float>(e->xb), tl, B, L, false));
-  else RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L, false));  // encoder: always exact fp32
+  else RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L, false, nullptr, 1.0, true));  // encoder: always exact fp32, K-split kernel
   HIPCHK(e, hipMemcpyAsync(e->encout.p, x, BL * H * 4, hipMemcpyDeviceToDevice, e->stream));
 
   // Variance adaptor, inference branch (U/layers.py:195-258)

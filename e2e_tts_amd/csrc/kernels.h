@@ -43,6 +43,11 @@ const char* conv_gemm_class(const ConvParams& p);  // profile class = the tile c
 double conv_gemm_flops(const ConvParams& p);
 double conv_gemm_bytes(const ConvParams& p);
 
+// The same convolution for the phoneme-level layers (encoder, predictors), exact fp32, K split four ways inside the workgroup with a
+// fixed reduction order (conv_ksplit.hip); needs p.wfrag in launch_f32_to_frag's order.  Used at every batch size for those layers.
+bool conv_ksplit_supported(const ConvParams& p);
+const char* launch_conv_ksplit(const ConvParams& p, hipStream_t s);
+
 // Fused masked self-attention on the packed QKV buffer of one FFT block.
 // qkv [B, N, 3H] (q | k | v, head h at columns h*dk .. (h+1)*dk of each third); keys >= lens[b] masked (-inf);
 // out [B, N, H]; query rows >= lens[b] are written as 0 (they are zeroed after the LayerNorm anyway).

@@ -24,12 +24,18 @@ namespace {
 // Two workgroups per CU (2 waves / SIMD): at DK = 192 the Q fragments (96 registers) and the O accumulators (96) leave little, and with a
 // one-argument __launch_bounds__ hipcc took 380 registers -- ONE wave per SIMD, one workgroup per CU: the 384 workgroups of the decoder
 // (B = 32, T = 768) then ran as a round of 256 and a round of 128 with every staging round trip exposed (0.5 ms per layer).
+// Workgroup barrier for LDS traffic only.  __syncthreads() is fence + s_barrier and the fence drains EVERY outstanding memory operation
+// (s_waitcnt vmcnt(0)) -- including the next chunk's K / V rows the split kernels have just requested, which is the round trip the
+// request was issued early to hide.  LDS writes and reads are counted by lgkmcnt alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int DK>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                         const int32_t* __restrict__ lens, int N, int H, float temperature) {
   constexpr int LDS_LD = DK + 4;
   constexpr int DT = DK / 32;  // 32-wide tiles of the head dimension
   constexpr int QQ = DK / 8;   // float4 fragments per query row and lane half
+  constexpr bool HALVES = DT % 2 == 0;
   __shared__ __attribute__((aligned(16))) float Ks[32 * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Vs[32 * LDS_LD];
 
@@ -83,18 +89,31 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     }
     __syncthreads();
 
-    // S^T[key][query] = sum_d K[key][d] Q[query][d]
-    f32x16 s;
+    // S^T[key][query] = sum_d K[key][d] Q[query][d].  With an even number of 32-wide head-dim tiles the sum is taken as
+    // (d < DK / 2) + (d >= DK / 2): the order attention_split_kernel below produces with one wavefront per half, so the two kernels
+    // give the same bits and the launcher may pick by grid size (two independent MFMA chains here, as a side effect).
+    f32x16 s, s1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int r = 0; r < 16; ++r) s[r] = 0.f, s1[r] = 0.f;
     const float* ka = Ks + li * LDS_LD + lh * 4;
 #pragma unroll
     for (int qq = 0; qq < QQ; ++qq) {
       const float4 a = *reinterpret_cast<const float4*>(ka + qq * 8);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[qq].x, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[qq].y, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[qq].z, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[qq].w, s, 0, 0, 0);
+      if (!HALVES || qq < QQ / 2) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[qq].x, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[qq].y, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[qq].z, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[qq].w, s, 0, 0, 0);
+      } else {
+        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[qq].x, s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[qq].y, s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[qq].z, s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[qq].w, s1, 0, 0, 0);
+      }
+    }
+    if constexpr (HALVES) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = s[r] + s1[r];
     }
     // scale, key-padding mask, online softmax (per query = per lane, both lane halves hold the same query)
     float mx = -INFINITY;
@@ -141,6 +160,175 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     float* orow = out + ((long long)b * N + q) * H + head * DK + 4 * lh;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        v.x = valid ? o[d][4 * g + 0] * inv : 0.f;
+        v.y = valid ? o[d][4 * g + 1] * inv : 0.f;
+        v.z = valid ? o[d][4 * g + 2] * inv : 0.f;
+        v.w = valid ? o[d][4 * g + 3] * inv : 0.f;
+        *reinterpret_cast<float4*>(orow + d * 32 + 8 * g) = v;
+      }
+  }
+}
+
+// ---- the same attention for SMALL grids (B = 1: the latency path; small batches): two wavefronts per 32-query tile, each owning HALF of
+// the head dimension, and QT = 2 query tiles per workgroup -- four wavefronts, one per SIMD, so that the halved chains really run side
+// by side (with 4 tiles x 2 halves on one CU each SIMD carried two half-chains: nothing gained) and twice the workgroups spread over CUs.  In attention_kernel one wavefront walks the keys of its 32 queries alone -- per 32-key chunk
+// 2 x DK / 2 dependent v_mfma_f32_32x32x2_f32 (192 at DK = 192: 12 k cycles = 5 us) -- and at B = 1, T = 768 only 48 wavefronts exist:
+// 24 chunks x 9 us = 225 us per decoder layer on 12 of 256 CUs.  Here the pair (w, w ^ 1) splits it: each computes the partial S^T over
+// its DK / 2 channels (Q fragments: half the registers), the two partial tiles meet in LDS and BOTH add them in the order
+// (d < DK / 2) + (d >= DK / 2) -- the order attention_kernel uses -- run the same softmax, and accumulate O^T for their own DK / 64
+// head-dim tiles.  Same bits as attention_kernel, half the chain, twice the wavefronts; and with half the registers there is room to
+// request the next chunk's K / V rows before this chunk's arithmetic (the staging round trip was exposed once per chunk).
+template <int DK, int QT>
+__global__ __launch_bounds__(QT * 128, 2) void attention_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 const int32_t* __restrict__ lens, int N, int H, float temperature) {
+  constexpr int LDS_LD = DK + 4;
+  constexpr int DH = DK / 2;    // head-dim channels per wavefront
+  constexpr int DTH = DH / 32;  // its 32-wide tiles
+  constexpr int QQH = DH / 8;   // its float4 Q fragments per lane
+  static_assert(DK % 64 == 0, "the split form needs an even number of 32-wide head-dim tiles");
+  constexpr int NF4 = 32 * (DK / 4);          // float4 per staged K (or V) chunk
+  constexpr int NTH = QT * 128;            // threads: QT query tiles x 2 halves x 64 lanes
+  constexpr int NLD = (NF4 + NTH - 1) / NTH;      // ... per thread
+  __shared__ __attribute__((aligned(16))) float Ks[32 * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Sx[QT * 2][16 * 64];  // each wavefront's partial S^T tile, register-major
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int qt = wave >> 1, part = wave & 1;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * 32) + qt * 32;
+  const int len = min(lens ? lens[b] : N, N);
+  if (blockIdx.x * (QT * 32) >= len) {  // a tile of padded queries only: their rows are zero (ragged batches)
+    for (int i = tid; i < QT * 32 * (DK / 4); i += NTH) {
+      const int q = blockIdx.x * (QT * 32) + i / (DK / 4);
+      if (q < N) *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + (i % (DK / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const int ld = 3 * H;
+  const float* base = qkv + (long long)b * N * ld;
+  const float* qp = base + head * DK + part * DH;
+  const float* kp = base + H + head * DK;
+  const float* vp = base + 2 * H + head * DK;
+
+  float4 qf[QQH];
+  {
+    const int qrow = min(q0 + li, N - 1);
+    const float* qr = qp + (long long)qrow * ld + lh * 4;
+#pragma unroll
+    for (int qq = 0; qq < QQH; ++qq) qf[qq] = *reinterpret_cast<const float4*>(qr + qq * 8);
+  }
+  f32x16 o[DTH];
+#pragma unroll
+  for (int d = 0; d < DTH; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  float4 kreg[NLD], vreg[NLD];
+  auto fetch = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = min(tid + i * NTH, NF4 - 1);
+      const int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
+      const int key = min(kc * 32 + r, N - 1);   // clamped: rows past N are zeroed when they are written to LDS
+      kreg[i] = *reinterpret_cast<const float4*>(kp + (long long)key * ld + c);
+      vreg[i] = *reinterpret_cast<const float4*>(vp + (long long)key * ld + c);
+    }
+  };
+  auto stash = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * NTH;
+      if (idx < NF4) {
+        const int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
+        const bool ok = kc * 32 + r < N;
+        // (component by component: a select between two float4 objects went through scratch memory)
+        const float4 kv = make_float4(ok ? kreg[i].x : 0.f, ok ? kreg[i].y : 0.f, ok ? kreg[i].z : 0.f, ok ? kreg[i].w : 0.f);
+        const float4 vv = make_float4(ok ? vreg[i].x : 0.f, ok ? vreg[i].y : 0.f, ok ? vreg[i].z : 0.f, ok ? vreg[i].w : 0.f);
+        *reinterpret_cast<float4*>(Ks + r * LDS_LD + c) = kv;
+        *reinterpret_cast<float4*>(Vs + r * LDS_LD + c) = vv;
+      }
+    }
+  };
+
+  const int nchunks = (len + 31) / 32;
+  fetch(0);
+  for (int kc = 0; kc < nchunks; ++kc) {
+    lds_barrier();  // every wavefront is done with the previous chunk's K / V
+    stash(kc);
+    lds_barrier();
+    if (kc + 1 < nchunks) fetch(kc + 1);
+
+    // partial S^T over this wavefront's half of the head dimension
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float* ka = Ks + li * LDS_LD + part * DH + lh * 4;
+#pragma unroll
+    for (int qq = 0; qq < QQH; ++qq) {
+      const float4 a = *reinterpret_cast<const float4*>(ka + qq * 8);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[qq].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[qq].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[qq].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[qq].w, s, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Sx[wave][r * 64 + lane] = s[r];
+    lds_barrier();
+    {
+      const float* s0 = Sx[wave & ~1];
+      const float* s1 = Sx[wave | 1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = s0[r * 64 + lane] + s1[r * 64 + lane];
+    }
+    // scale, key-padding mask, online softmax: as in attention_kernel, computed by both wavefronts of the pair
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = s[r] / temperature;
+      v = key < len ? v : -INFINITY;
+      s[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = expf(s[r] - m_new);
+      s[r] = pv;
+      psum += pv;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DTH; ++d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float a = Vs[key * LDS_LD + (part * DTH + d) * 32 + li];
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  const int q = q0 + li;
+  if (q < N) {
+    const bool valid = q < len;
+    const float inv = valid ? 1.0f / l_run : 0.f;
+    float* orow = out + ((long long)b * N + q) * H + head * DK + part * DH + 4 * lh;
+#pragma unroll
+    for (int d = 0; d < DTH; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 v;
@@ -337,6 +525,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(const float* _
   constexpr int VS = 36;       // words per Vt row: 16 (32 hi slots) + 16 (32 lo slots) + 4 pad
   constexpr int DT = DK / 32;  // 32-wide tiles of the head dimension
   constexpr int NS = DK / 16;  // k-steps of S^T = K . Q^T
+  constexpr bool HALVES = DT % 2 == 0;
   static_assert(DK % 32 == 0, "head dim must be a multiple of 32");
   __shared__ __attribute__((aligned(16))) unsigned Kh[32 * KS];
   __shared__ __attribute__((aligned(16))) unsigned Vt[DK * VS];
@@ -415,17 +604,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(const float* _
     __syncthreads();
 
     // S^T[key][query] = sum_d K[key][d] Q[query][d]
-    f32x16 s;
+    // (with an even number of head-dim tiles: as (d < DK / 2) + (d >= DK / 2), the order of attention_x3_split_kernel -- see the fp32 kernels)
+    f32x16 s, s1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int r = 0; r < 16; ++r) s[r] = 0.f, s1[r] = 0.f;
     const unsigned* ka = Kh + li * KS + lh * 4;
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) {
       const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ka + ks * 8));
       const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ka + DK / 2 + ks * 8));
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], s, 0, 0, 0);
+      if (!HALVES || ks < NS / 2) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], s, 0, 0, 0);
+      } else {
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], s1, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], s1, 0, 0, 0);
+      }
+    }
+    if constexpr (HALVES) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = s[r] + s1[r];
     }
     // scale, key-padding mask, online softmax (per query = per lane, both lane halves hold the same query)
     float mx = -INFINITY;
@@ -491,6 +691,190 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(const float* _
   }
 }
 
+// ---- split-precision attention for small grids: attention_split_kernel's arrangement (two wavefronts per 32-query tile, half the head
+// dimension each, partial S^T tiles added in LDS in attention_x3_kernel's order, next chunk's rows requested before this chunk's
+// arithmetic) on attention_x3_kernel's operands.  Same bits as attention_x3_kernel.
+template <int DK, int QT>
+__global__ __launch_bounds__(QT * 128, 2) void attention_x3_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                    const int32_t* __restrict__ lens, int N, int H, float temperature) {
+  constexpr int KS = DK + 4;
+  constexpr int VS = 36;
+  constexpr int DH = DK / 2, DTH = DH / 32, NSH = DH / 16;
+  static_assert(DK % 64 == 0, "the split form needs an even number of 32-wide head-dim tiles");
+  constexpr int NF4 = 32 * (DK / 4);
+  constexpr int NTH = QT * 128;            // threads: QT query tiles x 2 halves x 64 lanes
+  constexpr int NLD = (NF4 + NTH - 1) / NTH;
+  __shared__ __attribute__((aligned(16))) unsigned Kh[32 * KS];
+  __shared__ __attribute__((aligned(16))) unsigned Vt[DK * VS];
+  __shared__ __attribute__((aligned(16))) float Sx[QT * 2][16 * 64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int qt = wave >> 1, part = wave & 1;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * (QT * 32) + qt * 32;
+  const int len = min(lens ? lens[b] : N, N);
+  if (blockIdx.x * (QT * 32) >= len) {
+    for (int i = tid; i < QT * 32 * (DK / 4); i += NTH) {
+      const int q = blockIdx.x * (QT * 32) + i / (DK / 4);
+      if (q < N) *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + (i % (DK / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const int ld = 3 * H;
+  const float* base = qkv + (long long)b * N * ld;
+  const float* qp = base + head * DK + part * DH;
+  const float* kp = base + H + head * DK;
+  const float* vp = base + 2 * H + head * DK;
+
+  bf16x8_t qh[NSH], ql[NSH];
+  {
+    const int qrow = min(q0 + li, N - 1);
+    const float* qr = qp + (long long)qrow * ld + lh * 8;
+#pragma unroll
+    for (int s = 0; s < NSH; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(qr + s * 16), c = *reinterpret_cast<const float4*>(qr + s * 16 + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+      split8(v, qh[s], ql[s]);
+    }
+  }
+  f32x16 o[DTH];
+#pragma unroll
+  for (int d = 0; d < DTH; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float inv_temp = 1.0f / temperature;
+
+  float4 kreg[NLD], vreg[NLD];
+  auto fetch = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = min(tid + i * NTH, NF4 - 1);
+      const int r = idx / (DK / 4), c4 = idx % (DK / 4);
+      const int key = min(kc * 32 + r, N - 1);
+      kreg[i] = *reinterpret_cast<const float4*>(kp + (long long)key * ld + c4 * 4);
+      vreg[i] = *reinterpret_cast<const float4*>(vp + (long long)key * ld + c4 * 4);
+    }
+  };
+  auto stash = [&](int kc) __attribute__((always_inline)) {  // attention_x3_kernel's staging, from the registers
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * NTH;
+      if (idx < NF4) {
+        const int r = idx / (DK / 4), c4 = idx % (DK / 4);
+        const bool ok = kc * 32 + r < N;
+        const float4 kv = make_float4(ok ? kreg[i].x : 0.f, ok ? kreg[i].y : 0.f, ok ? kreg[i].z : 0.f, ok ? kreg[i].w : 0.f);
+        const float4 vv = make_float4(ok ? vreg[i].x : 0.f, ok ? vreg[i].y : 0.f, ok ? vreg[i].z : 0.f, ok ? vreg[i].w : 0.f);
+        const unsigned k0 = pk_bf16(kv.x, kv.y), k1 = pk_bf16(kv.z, kv.w);
+        const float kx = __builtin_bit_cast(float, k0 << 16), ky = __builtin_bit_cast(float, k0 & 0xffff0000u);
+        const float kz = __builtin_bit_cast(float, k1 << 16), kw = __builtin_bit_cast(float, k1 & 0xffff0000u);
+        *reinterpret_cast<uint2*>(Kh + r * KS + c4 * 2) = make_uint2(k0, k1);
+        *reinterpret_cast<uint2*>(Kh + r * KS + DK / 2 + c4 * 2) = make_uint2(pk_bf16(kv.x - kx, kv.y - ky), pk_bf16(kv.z - kz, kv.w - kw));
+        const int rr = (r & 3) + 4 * (r >> 3), h = (r >> 2) & 1;
+        const int slot = 16 * (rr >> 3) + 8 * h + (rr & 7);
+        unsigned short* vt = reinterpret_cast<unsigned short*>(Vt) + c4 * (VS * 2) + slot;
+        const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const __bf16 hb = (__bf16)vs[e];
+          const __bf16 lb = (__bf16)(vs[e] - (float)hb);
+          vt[e * (DK / 4) * (VS * 2)] = __builtin_bit_cast(unsigned short, hb);
+          vt[e * (DK / 4) * (VS * 2) + 32] = __builtin_bit_cast(unsigned short, lb);
+        }
+      }
+    }
+  };
+
+  const int nchunks = (len + 31) / 32;
+  fetch(0);
+  for (int kc = 0; kc < nchunks; ++kc) {
+    lds_barrier();
+    stash(kc);
+    lds_barrier();
+    if (kc + 1 < nchunks) fetch(kc + 1);
+
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const unsigned* ka = Kh + li * KS + part * (DH / 2) + lh * 4;   // this half's hi words; its lo words are DK / 2 further
+#pragma unroll
+    for (int ks = 0; ks < NSH; ++ks) {
+      const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ka + ks * 8));
+      const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ka + DK / 2 + ks * 8));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[ks], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[ks], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[ks], s, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Sx[wave][r * 64 + lane] = s[r];
+    lds_barrier();
+    {
+      const float* s0 = Sx[wave & ~1];
+      const float* s1 = Sx[wave | 1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = s0[r * 64 + lane] + s1[r * 64 + lane];
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = s[r] * inv_temp;
+      v = key < len ? v : -INFINITY;
+      s[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = __expf(m_run - m_new);
+    float psum = 0.f;
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pv[r] = __expf(s[r] - m_new);
+      psum += pv[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+    bf16x8_t ph[2], pl[2];
+    split8(pv, ph[0], pl[0]);
+    split8(pv + 8, ph[1], pl[1]);
+#pragma unroll
+    for (int d = 0; d < DTH; ++d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= corr;
+      const unsigned* va = Vt + ((li & 3) * (DK / 4) + (part * DTH + d) * 8 + (li >> 2)) * VS + lh * 4;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(va + s2 * 8));
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(va + 16 + s2 * 8));
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph[s2], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl[s2], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph[s2], o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  const int q = q0 + li;
+  if (q < N) {
+    const bool valid = q < len;
+    const float inv = valid ? 1.0f / l_run : 0.f;
+    float* orow = out + ((long long)b * N + q) * H + head * DK + part * DH + 4 * lh;
+#pragma unroll
+    for (int d = 0; d < DTH; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        v.x = valid ? o[d][4 * g + 0] * inv : 0.f;
+        v.y = valid ? o[d][4 * g + 1] * inv : 0.f;
+        v.z = valid ? o[d][4 * g + 2] * inv : 0.f;
+        v.w = valid ? o[d][4 * g + 3] * inv : 0.f;
+        *reinterpret_cast<float4*>(orow + d * 32 + 8 * g) = v;
+      }
+  }
+}
+
 }  // namespace
 
 const char* launch_rel_attention(const float* qkv, const float* ps, int ldp, const float* u, float* out, int B, int N, int H, int n_head,
@@ -524,6 +908,22 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
   // reference: temperature = np.power(d_k, 0.5), scores divided by it in fp32 (U/blocks/transformer.py:201,254)
   const float temperature = (float)sqrt((double)dk);
   dim3 grid((N + 127) / 128, n_head, B);
+  // The split form on 64-query workgroups (same bits, see attention_split_kernel).  fp32: at every grid size -- B = 1: 225 -> 135 us per
+  // decoder layer, B = 32: 2.50 -> 2.22 ms/step.  bf16x3: up to 512 workgroups (B = 16: 0.82 -> 0.75 ms/step); beyond, the 256-query
+  // workgroups of attention_x3_kernel win (B = 32: 0.95 against 1.33 ms), their K / V conversion shared by four times the queries.
+  // E2ETTS_ATT_SPLIT_MAX overrides both limits (0: never split -- what the bit-identity test runs its child process with).
+  static const long long split_env = getenv("E2ETTS_ATT_SPLIT_MAX") ? atoll(getenv("E2ETTS_ATT_SPLIT_MAX")) : -1;
+  const long long split_max = split_env >= 0 ? split_env : (x3 ? 512 : (1LL << 62));
+  dim3 gs((N + 63) / 64, n_head, B);
+  const bool split = (dk == 64 || dk == 128 || dk == 192) && (long long)gs.x * gs.y * gs.z <= split_max;
+  if (x3 && split) {
+    switch (dk) {
+      case 64: hipLaunchKernelGGL((attention_x3_split_kernel<64, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 128: hipLaunchKernelGGL((attention_x3_split_kernel<128, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      default: hipLaunchKernelGGL((attention_x3_split_kernel<192, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+    }
+    return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
+  }
   if (x3) {
     static const int nw = getenv("E2ETTS_ATT_NW") ? atoi(getenv("E2ETTS_ATT_NW")) : 8;  // tuning aid
     if (nw == 8) {
@@ -545,6 +945,14 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
       case 128: hipLaunchKernelGGL((attention_x3_kernel<128, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
       case 192: hipLaunchKernelGGL((attention_x3_kernel<192, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
       default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
+    }
+    return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
+  }
+  if (split) {
+    switch (dk) {
+      case 64: hipLaunchKernelGGL((attention_split_kernel<64, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 128: hipLaunchKernelGGL((attention_split_kernel<128, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      default: hipLaunchKernelGGL((attention_split_kernel<192, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
     }
     return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
   }

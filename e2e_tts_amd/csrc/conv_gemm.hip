@@ -665,10 +665,19 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
 // CUs idle -> 64 x 64.  half: on the fragment path, a 128 x 128 grid whose last round of workgroups (2 per CU = 512 at a time) is
 // mostly empty -- 576 tiles for a 24576 x 384 Linear are one full round and an eighth of a second -- runs as 64 x 128 tiles: twice
 // the workgroups at half the work, e.g. 3 half-rounds instead of 2 full ones.  Same per-wave MFMA : fragment ratio (MT = 2).
-bool few_rows(const ConvParams& p) { return tile_few_rows(p.B, p.T, p.Cout); }  // host_logic.h
+// (under one round of 128 x 128 tiles but many rows -- host_logic.h -- the fragment path takes 64 x 128, accumulate or not; without
+// fragment-order weights such a launch stays on 64 x 64)
+static bool under_round_many_rows(const ConvParams& p) {
+  return p.Cout > 64 && tiles_128(p.B, p.T, p.Cout) < 2 * 256 && tile_many_rows(p.B, p.T);
+}
+bool few_rows(const ConvParams& p) {  // host_logic.h
+  return tile_few_rows(p.B, p.T, p.Cout) || (!p.wfrag && under_round_many_rows(p));
+}
 bool half_rows(const ConvParams& p) {
   static const bool on = !(getenv("E2ETTS_HALF_ROWS") && atoi(getenv("E2ETTS_HALF_ROWS")) == 0);  // tuning aid
-  if (!on || !p.wfrag || p.accumulate) return false;
+  if (!p.wfrag) return false;
+  if (under_round_many_rows(p)) return true;
+  if (!on || p.accumulate) return false;
   return tile_half_rows(p.B, p.T, p.Cout);
 }
 

@@ -135,9 +135,15 @@ inline long long tiles_128(int B, int T, int Cout) {  // 128 x 128 tiles of the 
   const long long t = ((long long)T + 127) / 128 * (((long long)Cout + 127) / 128);
   return t > (1LL << 40) / (B > 0 ? B : 1) ? (1LL << 40) : t * B;
 }
-inline bool tile_few_rows(int B, int T, int Cout) { return Cout > 64 && tiles_128(B, T, Cout) < 2 * 256; }
+// Under one round of 128 x 128 tiles but >= 6144 rows (the first vocoder stage at B = 1 .. 2, 6144 x 256: 96 tiles): 64 x 64 tiles are
+// 384 workgroups whose waves each fetch their own weight fragments for ONE 32 x 32 MFMA tile -- that launch waits on L2 bandwidth
+// (540 MB of fragments in 55 us) -- so those run as 64 x 128 too: 192 workgroups, two MFMA row tiles per fragment (B = 1 step: 9.46 ->
+// 9.05 ms fp32, 5.21 -> 5.11 ms bf16x3; B = 4: -4 %).  With fewer rows (the decoder at B <= 4, the encoder) 64 x 64 stayed ahead.
+inline bool tile_many_rows(int B, int T) { return (long long)B * T >= 6144; }
+inline bool tile_few_rows(int B, int T, int Cout) { return Cout > 64 && tiles_128(B, T, Cout) < 2 * 256 && !tile_many_rows(B, T); }
 inline bool tile_half_rows(int B, int T, int Cout) {
   if (Cout <= 64 || tile_few_rows(B, T, Cout)) return false;
+  if (tiles_128(B, T, Cout) < 2 * 256) return true;  // under one round, many rows
   const long long wg = tiles_128(B, T, Cout), slots = 2 * 256;
   const long long r128 = (wg + slots - 1) / slots, r64 = (2 * wg + slots - 1) / slots;
   return 0.5 * 1.06 * (double)r64 < (double)r128;

@@ -755,6 +755,50 @@ def test_fp32_fragment_path_is_bit_identical_to_the_lds_weight_tile(tmp_path):
     np.testing.assert_array_equal(o["pcm"], pcm)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_attention_split_form_is_bit_identical_to_one_wavefront_per_query_tile(tmp_path, precision):
+    """Small grids (this B = 3 fixture, the B = 1 latency path) run attention with two wavefronts per 32-query tile, half the head
+    dimension each (attention_split_kernel / attention_x3_split_kernel); large ones with one (attention_kernel / attention_x3_kernel),
+    which adds its two half sums in the same order.  The child process is held to the one-wavefront kernels (E2ETTS_ATT_SPLIT_MAX=0, read
+    once per process): durations, buckets and mel must come out bit for bit the same as from this process's split kernels."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    g = load_golden("full_b3")
+    cfg, eng = engine_for(g, "full_b3")
+    eng.set_precision(precision)
+    spk = np.array([int(g["speaker"])], np.int64)
+    d, p, e = (float(x) for x in g["controls"])
+    r = eng.acoustic(g["ids"], g["lens"], spk, d, p, e, want=("dur", "mel_lens", "pitch_idx", "energy_idx"))
+    mel, mel_post = eng.fetch_mel(r["B"], r["T"])
+    eng.set_precision("fp32")
+    script = tmp_path / "att_child.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "from conftest import load_golden, states_for\n"
+        "from e2e_tts_amd import config as cfgmod\n"
+        "from e2e_tts_amd.runtime import engine_from_states\n"
+        "g = load_golden('full_b3'); cfg, ac, voc = states_for(g, 'full_b3')\n"
+        "eng = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)\n"
+        f"eng.set_precision({precision!r})\n"
+        "spk = np.array([int(g['speaker'])], np.int64); d, p, e = (float(x) for x in g['controls'])\n"
+        "r = eng.acoustic(g['ids'], g['lens'], spk, d, p, e, want=('dur', 'mel_lens', 'pitch_idx', 'energy_idx'))\n"
+        "mel, mel_post = eng.fetch_mel(r['B'], r['T'])\n"
+        "np.savez(sys.argv[1], mel=mel, mel_post=mel_post, dur=r['dur'], pitch_idx=r['pitch_idx'], energy_idx=r['energy_idx'])\n")
+    out = tmp_path / "att.npz"
+    env = dict(os.environ, E2ETTS_ATT_SPLIT_MAX="0")
+    rr = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=900)
+    assert rr.returncode == 0, rr.stderr[-3000:]
+    o = np.load(out)
+    for k in ("dur", "pitch_idx", "energy_idx"):
+        np.testing.assert_array_equal(o[k], r[k])
+    np.testing.assert_array_equal(o["mel"], mel)
+    np.testing.assert_array_equal(o["mel_post"], mel_post)
+    assert np.abs(mel).max() > 0.1
+
+
 def test_fused_kernels_on_unusual_resblock_geometry():
     """The fused ResBlock kernels take kernel sizes and dilations from the config (reference V/generator.py:27-31, V/layers.py:11-31), not
     the V1 constants: a generator with kernel sizes (3, 5, 9), dilations (1, 2, 4) / (2, 6, 3) / (1, 1, 1) and stages of 64 / 32 / 16 / 8

@@ -132,6 +132,7 @@ def test_tile_choice(harness):
     assert run(harness, "tiles", 32, 6144, 256) == "few=0 half=0"
     assert run(harness, "tiles", 32, 128, 384) == "few=1 half=0"
     assert run(harness, "tiles", 1, 768, 1024) == "few=1 half=0"
+    assert run(harness, "tiles", 1, 6144, 256) == "few=0 half=1"      # under one round of 128 x 128 tiles, many rows: 64 x 128
     assert run(harness, "tiles", 32, 768, 64) == "few=0 half=0"
     for args in ((0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF), (1, 1, 65), (4096, 1 << 20, 8192)):
         assert run(harness, "tiles", *args).startswith("few=")

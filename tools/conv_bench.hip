@@ -1,6 +1,6 @@
 // Micro-benchmark + self-check of conv_gemm on the shapes of the B = 32, T = 768 workload.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I e2e_tts_amd/csrc tools/conv_bench.hip e2e_tts_amd/csrc/conv_gemm.hip e2e_tts_amd/csrc/small_kernels.hip -o tools/bin/conv_bench
-// Usage: conv_bench [reps] [name-filter | -] [f32 | f32f | x3 | x3f]   (f32f / x3f: weights in MFMA-fragment order)
+// Usage: [CONV_BENCH_B=1] conv_bench [reps] [name-filter | -] [f32 | f32f | x3 | x3f]   (f32f / x3f: weights in MFMA-fragment order)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -145,7 +145,7 @@ int main(int argc, char** argv) {
     }
   }
   // ---- timing
-  const int B = 32;
+  const int B = getenv("CONV_BENCH_B") ? atoi(getenv("CONV_BENCH_B")) : 32;  // 1: the latency path's launches
   Shape shapes[] = {
       {"s1 k3d1", B, 6144, 256, 256, 3, 1, false, false, 0.1f}, {"s1 k11d5", B, 6144, 256, 256, 11, 5, false, false, 0.1f},
       {"s1 k11 c2+res", B, 6144, 256, 256, 11, 1, true, false, 1.0f},

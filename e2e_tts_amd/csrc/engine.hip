@@ -285,6 +285,18 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0, bool ksplit = f
     KCHK(e, launch_conv_ksplit(p, e->stream));
     return E2ETTS_OK;
   }
+  // few rows (small batches, the B = 1 latency path) on fragment-order weights: conv_rows -- conv_gemm's arithmetic, MFMA for MFMA, with
+  // one wavefront per 32-row tile and no workgroup barrier (conv_ksplit.hip).  Same bits: E2ETTS_ROWS=0 (tuning aid) changes speed only.
+  // Taken where it measured ahead: convolutions (KW >= 3: a k = 1 Linear stages a slab per 6 MFMAs here, conv_gemm's multi-chunk items do
+  // better) on grids of at most one 64 x 64 workgroup per CU -- B = 1: the decoder's k = 9 convolution 63 -> 40 us, the postnet's 52 -> 36;
+  // at B = 4 conv_gemm's several workgroups per CU already hide what this kernel avoids.
+  static const bool rows_on = !(getenv("E2ETTS_ROWS") && atoi(getenv("E2ETTS_ROWS")) == 0);
+  const long long wg64 = (long long)((p.T + 63) / 64) * p.B * ((p.Cout + 63) / 64);
+  if (rows_on && p.KW >= 3 && wg64 <= 256 && tile_few_rows(p.B, p.T, p.Cout) && conv_rows_supported(p)) {
+    ProfScope ps(e, fine && e->prof_on ? fname : (p.x3 ? "conv_x3_rows" : "conv_rows"), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
+    KCHK(e, launch_conv_rows(p, e->stream));
+    return E2ETTS_OK;
+  }
   ProfScope ps(e, fine && e->prof_on ? fname : conv_gemm_class(p), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
   KCHK(e, launch_conv_gemm(p, e->stream));
   return E2ETTS_OK;

@@ -48,6 +48,11 @@ double conv_gemm_bytes(const ConvParams& p);
 bool conv_ksplit_supported(const ConvParams& p);
 const char* launch_conv_ksplit(const ConvParams& p, hipStream_t s);
 
+// conv_gemm's few-rows launches (small batches, the B = 1 latency path) with one wavefront per 32-row tile, private slabs, no workgroup
+// barrier and a deep ring of weight fragments (conv_ksplit.hip); the same bits as conv_gemm.  Needs p.wfrag (either fragment order).
+bool conv_rows_supported(const ConvParams& p);
+const char* launch_conv_rows(const ConvParams& p, hipStream_t s);
+
 // Fused masked self-attention on the packed QKV buffer of one FFT block.
 // qkv [B, N, 3H] (q | k | v, head h at columns h*dk .. (h+1)*dk of each third); keys >= lens[b] masked (-inf);
 // out [B, N, H]; query rows >= lens[b] are written as 0 (they are zeroed after the LayerNorm anyway).

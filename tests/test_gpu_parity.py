@@ -760,7 +760,9 @@ def test_attention_split_form_is_bit_identical_to_one_wavefront_per_query_tile(t
     """Small grids (this B = 3 fixture, the B = 1 latency path) run attention with two wavefronts per 32-query tile, half the head
     dimension each (attention_split_kernel / attention_x3_split_kernel); large ones with one (attention_kernel / attention_x3_kernel),
     which adds its two half sums in the same order.  The child process is held to the one-wavefront kernels (E2ETTS_ATT_SPLIT_MAX=0, read
-    once per process): durations, buckets and mel must come out bit for bit the same as from this process's split kernels."""
+    once per process): durations, buckets and mel must come out bit for bit the same as from this process's split kernels.  The child
+    also runs its few-rows convolutions on conv_gemm's 64 x 64 tile (E2ETTS_ROWS=0) where this process takes conv_rows -- one wavefront
+    per 32-row tile, no workgroup barrier, the same MFMA sequence."""
     import os
     import subprocess
     import sys
@@ -788,7 +790,7 @@ def test_attention_split_form_is_bit_identical_to_one_wavefront_per_query_tile(t
         "mel, mel_post = eng.fetch_mel(r['B'], r['T'])\n"
         "np.savez(sys.argv[1], mel=mel, mel_post=mel_post, dur=r['dur'], pitch_idx=r['pitch_idx'], energy_idx=r['energy_idx'])\n")
     out = tmp_path / "att.npz"
-    env = dict(os.environ, E2ETTS_ATT_SPLIT_MAX="0")
+    env = dict(os.environ, E2ETTS_ATT_SPLIT_MAX="0", E2ETTS_ROWS="0")
     rr = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=900)
     assert rr.returncode == 0, rr.stderr[-3000:]
     o = np.load(out)

@@ -27,130 +27,6 @@ namespace {
 constexpr int LDK = 36;        // LDS row stride (floats): 32 channels + 4 pad
 constexpr int KS_MAX_HALO = 16;  // dil * (KW - 1) supported (k = 9: 8)
 
-template <int NT>
-__global__ __launch_bounds__(256) void conv_ksplit_kernel(const ConvParams p) {
-  constexpr int SROWS = 32 + KS_MAX_HALO;
-  __shared__ __attribute__((aligned(16))) float slab[4][SROWS * LDK];   // one private slab per wave
-  __shared__ __attribute__((aligned(16))) float red[3][NT][16 * 64];    // partial sums of waves 1..3
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.x * 32;
-  const int n0 = blockIdx.y * (32 * NT);
-  const int halo = p.dil * (p.KW - 1);
-  const int srows = 32 + halo;
-  const int nchunk = (p.Cin + 31) / 32;
-  const int ntile32 = (p.Cout + 31) / 32;
-  const float* in_b = p.in + (long long)b * p.in_bs;
-  const __amdgpu_buffer_rsrc_t in_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((long long)p.T * p.in_ld * 4), 0x00020000);
-  // fragment order [32-column tile][tap][chunk][q 0..3][lane][4 floats]: 1 KiB per (tile, tap, chunk, q)
-  const __amdgpu_buffer_rsrc_t wf_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.wfrag), 0, (int)((long long)ntile32 * p.KW * nchunk * 4096), 0x00020000);
-  int fnt[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) fnt[n] = min(n0 / 32 + n, ntile32 - 1);
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-
-  float* my = slab[wave];
-  const int srow = lane >> 3, sc4 = (lane & 7) * 4;   // staging: 8 lanes per row, 8 rows per pass
-  float4 bfr[2][4][NT];                               // weight fragments of the current and the next tap
-  auto load_frag = [&](int buf, int chunk, int j) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int soff = (((fnt[n] * p.KW + j) * nchunk + chunk) * 4 + q) * 1024;
-        bfr[buf][q][n] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
-      }
-  };
-
-  for (int c = wave; c < nchunk; c += 4) {
-    load_frag(0, c, 0);
-    // this wave's slab: rows t0 - pad .. + srows of channels 32 c .. + 31 (zero outside [0, T) and beyond Cin)
-    for (int r0 = 0; r0 < srows; r0 += 8) {
-      const int r = r0 + srow;
-      const int t = t0 - p.pad + r;
-      const int ch = c * 32 + sc4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < srows && t >= 0 && t < p.T && ch < p.Cin)
-        v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (t * p.in_ld + ch) * 4, 0, 0));
-      if (r < srows) *reinterpret_cast<float4*>(my + r * LDK + sc4) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();   // the slab was written by other lanes of this wave: keep the reads below behind the writes
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // taps in pairs so that the fragment buffer of a tap is a compile-time index; the next tap's fragments are requested a tap ahead
-    auto tap = [&](auto buf, int j) {
-      constexpr int P = decltype(buf)::value;
-      const float* a_base = my + (li + j * p.dil) * LDK + lh * 4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 a = *reinterpret_cast<const float4*>(a_base + q * 8);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const float4 w = bfr[P][q][n];
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc[n], 0, 0, 0);
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc[n], 0, 0, 0);
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc[n], 0, 0, 0);
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc[n], 0, 0, 0);
-        }
-      }
-    };
-    int j = 0;
-    for (; j + 1 < p.KW; j += 2) {
-      load_frag(1, c, j + 1);
-      tap(std::integral_constant<int, 0>{}, j);
-      if (j + 2 < p.KW) load_frag(0, c, j + 2);
-      tap(std::integral_constant<int, 1>{}, j + 1);
-    }
-    if (j < p.KW) tap(std::integral_constant<int, 0>{}, j);   // odd KW: the last tap's fragments are in buffer 0
-    __builtin_amdgcn_wave_barrier();   // every lane is done reading the slab before the next chunk overwrites it
-  }
-
-  // ---- ((P0 + P1) + (P2 + P3)): waves 1..3 hand their partial sums over, wave 0 adds them in that order and runs the epilogue
-  if (wave > 0) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[wave - 1][n][r * 64 + lane] = acc[n][r];
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  const int len = p.lens ? p.lens[b] : p.T;
-  float* out_b = p.out + (long long)b * p.out_bs;
-  const float* res_b = p.res ? p.res + (long long)b * p.res_bs : nullptr;
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = n0 + n * 32 + li;
-    const bool col_ok = col < p.Cout;
-    const float bias = (p.bias && col_ok) ? p.bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float p01 = acc[n][r] + red[0][n][r * 64 + lane];
-      const float p23 = red[1][n][r * 64 + lane] + red[2][n][r * 64 + lane];
-      float v = (p01 + p23) + bias;
-      if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-      else if (p.act == ACT_TANH) v = tanhf(v);
-      else if (p.act == ACT_LRELU) v = v >= 0.f ? v : v * p.act_slope;
-      else if (p.act == ACT_SWISH) v = v * (1.0f / (1.0f + expf(-v)));
-      if (t < p.T && col_ok) {
-        if (res_b) v += res_b[(long long)t * p.res_ld + col];
-        if (t >= len) v = 0.f;
-        out_b[(long long)t * p.out_ld + col] = v;
-      }
-    }
-  }
-}
-
-
 // ---- conv_rows: the few-rows launches of the FRAME-level layers (the decoder's FFT blocks, mel_linear, the postnet at small batches:
 // the B = 1 latency path) -- conv_gemm's 64 x 64 tile otherwise.  Same arithmetic as conv_gemm, MFMA for MFMA (chunk-major, tap-minor,
 // one accumulator chain per 32 x 32 tile; bf16x3: lo x hi, hi x lo, hi x hi), so the two give the same bits and the choice is free per
@@ -184,8 +60,11 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {  
   lo.y = pack_bf16(v.z - hz, v.w - hw);
 }
 
-template <int NT, int MODE, int D>
+// SPLITK (conv_ksplit, fp32 only): the four wavefronts share ONE 32-row tile and take the 32-channel chunks round-robin (wave w: chunks
+// w, w + 4, ...); their partial sums meet in LDS and wave 0 adds them as ((P0 + P1) + (P2 + P3)) -- see the head of this file.
+template <int NT, int MODE, int D, bool SPLITK>
 __global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, const int rg, const int ct) {
+  static_assert(!SPLITK || MODE == 0, "the K-split form serves the exact-fp32 phoneme-level layers");
   constexpr bool X3 = MODE != 0;
   constexpr bool SPLIT = MODE == 1;
   constexpr int KSN = X3 ? 2 : 4;  // fragment groups per 32-channel chunk: 2 k-steps of 16 (bf16 MFMA) or 4 x (4 MFMAs of k = 2)
@@ -199,15 +78,17 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, cons
   // column tile fastest: with ct a multiple of 8 the workgroups of one XCD (id % 8) share an eighth of the weights
   const int cy = blockIdx.x % ct, g = blockIdx.x / ct;
   const int b = g / rg;
-  const int t0 = (g - b * rg) * 128 + wave * 32;
+  const int t0 = SPLITK ? (g - b * rg) * 32 : (g - b * rg) * 128 + wave * 32;   // rg: row tiles of 32 (SPLITK) or groups of 128
   const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
-  if (t0 >= t_act) return;   // no workgroup barrier in this kernel: a wavefront without rows simply leaves
+  if (t0 >= t_act) return;   // !SPLITK: no workgroup barrier, a wavefront without rows simply leaves; SPLITK: uniform for the workgroup
   const int n0 = cy * (32 * NT);
   const int halo = p.dil * (p.KW - 1);
   const int srows = 32 + halo;
   const int nchunk = (p.Cin + 31) / 32;
   const int ntile32 = (p.Cout + 31) / 32;
-  const int nu = nchunk * p.KW;
+  const int nmy = SPLITK ? (nchunk - wave + 3) / 4 : nchunk;   // this wavefront's chunks: cc(0), cc(1), ...
+  auto cc = [&](int c) __attribute__((always_inline)) { return SPLITK ? wave + 4 * c : c; };
+  const int nu = nmy * p.KW;
   const float* in_b = p.in + (long long)b * p.in_bs;
   const __amdgpu_buffer_rsrc_t in_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, (int)((long long)p.T * p.in_ld * 4), 0x00020000);
@@ -272,19 +153,19 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, cons
 
   float* const slab0 = slab[wave][0];
   int buf = 0;   // which half of this wave's double buffer holds the current chunk (an index, not a swapped pointer: that went via scratch)
-  stage_load(0);
+  stage_load(cc(0));
   int pc = 0, pj = 0;  // (chunk, tap) of the unit whose fragments are requested next; wraps (requests past the end are never used)
   auto advance_p = [&]() __attribute__((always_inline)) {
     if (++pj == p.KW) {
       pj = 0;
-      if (++pc == nchunk) pc = 0;
+      if (++pc == nmy) pc = 0;
     }
   };
   static_for<D>([&](auto slot) __attribute__((always_inline)) {
-    load_frag(slot, pc, pj);
+    load_frag(slot, cc(pc), pj);
     advance_p();
   });
-  stage_store(0, slab0);
+  stage_store(cc(0), slab0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS written by other lanes of THIS wave: order the reads behind the writes
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -292,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, cons
   int c = 0, j = 0;
   auto unit = [&](auto slot, const int c, const int j, const int buf) __attribute__((always_inline)) {
     constexpr int S = decltype(slot)::value;
-    if (j == 0 && c + 1 < nchunk) stage_load(c + 1);   // the next chunk's rows: in registers until this chunk's last tap
+    if (j == 0 && c + 1 < nmy) stage_load(cc(c + 1));   // the next chunk's rows: in registers until this chunk's last tap
     const float* a_base = slab0 + buf * (SROWS * LDK) + (li + j * p.dil) * LDK + lh * 4;
     if constexpr (X3) {
 #pragma unroll
@@ -324,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, cons
         }
       }
     }
-    load_frag(slot, pc, pj);   // this slot is consumed: the unit D ahead
+    load_frag(slot, cc(pc), pj);   // this slot is consumed: the unit D ahead
     advance_p();
   };
   // (spelled out, with the counters updated and the wavefront fences issued HERE rather than inside a lambda: with both inside one,
@@ -334,8 +215,8 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, cons
     if (u0 + S < nu) {                                                    \
       unit(std::integral_constant<int, S>{}, c, j, buf);                  \
       if (j == p.KW - 1) {                                                \
-        if (c + 1 < nchunk) {                                             \
-          stage_store(c + 1, slab0 + (buf ^ 1) * (SROWS * LDK));          \
+        if (c + 1 < nmy) {                                                \
+          stage_store(cc(c + 1), slab0 + (buf ^ 1) * (SROWS * LDK));      \
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          \
           __builtin_amdgcn_wave_barrier();                                \
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          \
@@ -354,10 +235,48 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, cons
 #undef E2ETTS_UNIT
   static_assert(D <= 8, "ring depth");
 
-  // ---- epilogue: conv_gemm's order and formulas (bias, max(v, v * slope) for none / ReLU / leaky ReLU, tanh, swish, residual, mask)
   const int len = p.lens ? p.lens[b] : p.T;
   float* out_b = p.out + (long long)b * p.out_bs;
   const float* res_b = p.res ? p.res + (long long)b * p.res_bs : nullptr;
+  if constexpr (SPLITK) {
+    // ---- ((P0 + P1) + (P2 + P3)): waves 1..3 leave their partial sums in their own (now idle) slab, wave 0 adds them in that order
+    static_assert(2 * SROWS * LDK >= NT * 16 * 64, "a wave's slab must hold its partial tile");
+    if (wave > 0) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab0[(n * 16 + r) * 64 + lane] = acc[n][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const float* r1 = slab[1][0];
+    const float* r2 = slab[2][0];
+    const float* r3 = slab[3][0];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = n0 + n * 32 + li;
+      const bool col_ok = col < p.Cout;
+      const float bias = (p.bias && col_ok) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float p01 = acc[n][r] + r1[(n * 16 + r) * 64 + lane];
+        const float p23 = r2[(n * 16 + r) * 64 + lane] + r3[(n * 16 + r) * 64 + lane];
+        float v = (p01 + p23) + bias;
+        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == ACT_TANH) v = tanhf(v);
+        else if (p.act == ACT_LRELU) v = v >= 0.f ? v : v * p.act_slope;
+        else if (p.act == ACT_SWISH) v = v * (1.0f / (1.0f + expf(-v)));
+        if (t < p.T && col_ok) {
+          if (res_b) v += res_b[(long long)t * p.res_ld + col];
+          if (t >= len) v = 0.f;
+          out_b[(long long)t * p.out_ld + col] = v;
+        }
+      }
+    }
+    return;
+  }
+  // ---- epilogue: conv_gemm's order and formulas (bias, max(v, v * slope) for none / ReLU / leaky ReLU, tanh, swish, residual, mask)
   const float eslope = p.act == ACT_RELU ? 0.f : (p.act == ACT_LRELU ? p.act_slope : 1.f);
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -397,13 +316,11 @@ const char* launch_conv_ksplit(const ConvParams& p, hipStream_t s) {
   const int rt = (p.T + 31) / 32;
   // 64-column tiles halve the slab traffic per MFMA; 32-column tiles when that would leave most CUs without a workgroup
   const bool wide = p.Cout > 32 && (long long)rt * ((p.Cout + 63) / 64) * p.B >= 256;
-  if (wide) {
-    dim3 grid(rt, (p.Cout + 63) / 64, p.B);
-    hipLaunchKernelGGL(conv_ksplit_kernel<2>, grid, dim3(256), 0, s, p);
-  } else {
-    dim3 grid(rt, (p.Cout + 31) / 32, p.B);
-    hipLaunchKernelGGL(conv_ksplit_kernel<1>, grid, dim3(256), 0, s, p);
-  }
+  const int ct = wide ? (p.Cout + 63) / 64 : (p.Cout + 31) / 32;
+  const long long nwg = (long long)ct * rt * p.B;
+  if (nwg >= (1LL << 31)) return "conv_ksplit: grid too large";
+  if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 0, 3, true>), dim3((unsigned)nwg), dim3(256), 0, s, p, rt, ct);
+  else hipLaunchKernelGGL((conv_rows_kernel<1, 0, 3, true>), dim3((unsigned)nwg), dim3(256), 0, s, p, rt, ct);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_ksplit: launch failed";
 }
 
@@ -429,14 +346,14 @@ const char* launch_conv_rows(const ConvParams& p, hipStream_t s) {
   const dim3 grid((unsigned)nwg), block(256);
   // ring depth: a unit is 16 MFMAs of 64 cycles in fp32, 6 (bf16x3) or 2 (bf16) of 32 in the bf16 modes
   if (p.x3 == 0) {
-    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 0, 3>), grid, block, 0, s, p, rg, ct);
-    else hipLaunchKernelGGL((conv_rows_kernel<1, 0, 3>), grid, block, 0, s, p, rg, ct);
+    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 0, 3, false>), grid, block, 0, s, p, rg, ct);
+    else hipLaunchKernelGGL((conv_rows_kernel<1, 0, 3, false>), grid, block, 0, s, p, rg, ct);
   } else if (p.x3 == 1) {
-    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 1, 4>), grid, block, 0, s, p, rg, ct);
-    else hipLaunchKernelGGL((conv_rows_kernel<1, 1, 6>), grid, block, 0, s, p, rg, ct);
+    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 1, 4, false>), grid, block, 0, s, p, rg, ct);
+    else hipLaunchKernelGGL((conv_rows_kernel<1, 1, 6, false>), grid, block, 0, s, p, rg, ct);
   } else {
-    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 2, 4>), grid, block, 0, s, p, rg, ct);
-    else hipLaunchKernelGGL((conv_rows_kernel<1, 2, 6>), grid, block, 0, s, p, rg, ct);
+    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 2, 4, false>), grid, block, 0, s, p, rg, ct);
+    else hipLaunchKernelGGL((conv_rows_kernel<1, 2, 6, false>), grid, block, 0, s, p, rg, ct);
   }
   return hipGetLastError() == hipSuccess ? nullptr : "conv_rows: launch failed";
 }

@@ -34,7 +34,13 @@ def kernel_class(name: str):
     m = re.search(r"resblock_chain_kernel<\d+, (\d+)", name)
     if m:
         return "resblock_chain_" + m.group(1)
-    for key, cls in (("rel_attention_kernel", "rel_attention"), ("attention_x3_kernel", "attention_x3"), ("attention_kernel", "attention"),
+    m = re.search(r"conv_rows_kernel<\d+, (\d+), \d+, (true|false|1|0)", name)
+    if m:  # SPLITK: the phoneme-level K-split form; otherwise the few-rows form of conv_gemm's arithmetic
+        if m.group(2) in ("true", "1"):
+            return "conv_ksplit"
+        return "conv_rows" if m.group(1) == "0" else "conv_x3_rows"
+    for key, cls in (("rel_attention_kernel", "rel_attention"), ("attention_x3_split_kernel", "attention_x3"), ("attention_x3_kernel", "attention_x3"),
+                     ("attention_split_kernel", "attention"), ("attention_kernel", "attention"),
                      ("layernorm_kernel", "layernorm"), ("conv_post_kernel", "conv_post"), ("dwconv_swish_kernel", "dwconv_swish"),
                      ("glu_kernel", "glu")):
         if key in name:

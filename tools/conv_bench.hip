@@ -1,6 +1,9 @@
 // Micro-benchmark + self-check of conv_gemm on the shapes of the B = 32, T = 768 workload.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I e2e_tts_amd/csrc tools/conv_bench.hip e2e_tts_amd/csrc/conv_gemm.hip e2e_tts_amd/csrc/small_kernels.hip -o tools/bin/conv_bench
-// Usage: [CONV_BENCH_B=1] conv_bench [reps] [name-filter | -] [f32 | f32f | x3 | x3f]   (f32f / x3f: weights in MFMA-fragment order)
+// Usage: [CONV_BENCH_B=1] [CONV_BENCH_KERNEL=rows|ksplit] conv_bench [reps] [name-filter | -] [f32 | f32f | x3 | x3f]
+//   (f32f / x3f: weights in MFMA-fragment order; CONV_BENCH_KERNEL: check and time conv_ksplit.hip's kernels -- they need f32f / x3f --
+//   instead of conv_gemm where they support the shape)
+// Build adds e2e_tts_amd/csrc/conv_ksplit.hip to the line below.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -132,8 +135,12 @@ int main(int argc, char** argv) {
         if (fm) { printf("%s\n", fm); return 1; }
         p.wfrag = dwf;
       }
-      const char* m = launch_conv_gemm(p, s);
+      const char* kern = getenv("CONV_BENCH_KERNEL");
+      const bool use_rows = kern && !strcmp(kern, "rows") && conv_rows_supported(p);
+      const bool use_ks = kern && !strcmp(kern, "ksplit") && conv_ksplit_supported(p);
+      const char* m = use_rows ? launch_conv_rows(p, s) : (use_ks ? launch_conv_ksplit(p, s) : launch_conv_gemm(p, s));
       if (m) { printf("%s: %s\n", c.name, m); return 1; }
+      if (kern) printf("  [%s] ", use_rows ? "conv_rows" : (use_ks ? "conv_ksplit" : "conv_gemm (shape not supported by the asked kernel)"));
       hipLaunchKernelGGL(naive_conv, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, q);
       CK(hipStreamSynchronize(s));
       std::vector<float> a(nout), r(nout);
@@ -190,9 +197,13 @@ int main(int argc, char** argv) {
     p.in_slope = c.slope; p.act = c.res ? ACT_NONE : ACT_LRELU; p.act_slope = 0.1f; p.accumulate = c.acc; p.out_div = 1.f;
     p.x3 = x3; if (x3) p.w = dwx3;
     if (frag || frag32) p.wfrag = dwx3;  // timing only: any finite pattern, same footprint
-    for (int i = 0; i < 2; ++i) { const char* m = launch_conv_gemm(p, s); if (m) { printf("%s: %s\n", c.name, m); return 1; } }
+    const char* kern = getenv("CONV_BENCH_KERNEL");
+    const bool use_rows = kern && !strcmp(kern, "rows") && conv_rows_supported(p);
+    const bool use_ks = kern && !strcmp(kern, "ksplit") && conv_ksplit_supported(p);
+    auto launch = [&]() { return use_rows ? launch_conv_rows(p, s) : (use_ks ? launch_conv_ksplit(p, s) : launch_conv_gemm(p, s)); };
+    for (int i = 0; i < 2; ++i) { const char* m = launch(); if (m) { printf("%s: %s\n", c.name, m); return 1; } }
     CK(hipEventRecord(e0, s));
-    for (int i = 0; i < reps; ++i) launch_conv_gemm(p, s);
+    for (int i = 0; i < reps; ++i) launch();
     CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     double fl = conv_gemm_flops(p);

@@ -105,18 +105,15 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
 // CPI > 0 (KW == 1 launches on the fragment path, Cin a multiple of 32 CPI): a work item stages CPI 32-channel chunks at once, as
 //        CPI planes of the slab, and the loop walks them like taps.  A plain Linear has ONE tap per chunk, i.e. two workgroup
 //        barriers and a staging pass per 24 MFMAs of a wave; with CPI planes it is one per 24 CPI.  Same chunk order, same bits.
-// Waves per SIMD the register allocation must allow.  The exact-fp32 kernel on fragment-order weights keeps only its slab in LDS
-// (<= 28 KB), so a third workgroup would fit on the CU if the kernel stayed within 168 VGPRs (tuning knob E2ETTS_F32_OCC).
-// Measured (tools/conv_bench f32f, same box): 3 waves / SIMD gain 2 % on the k = 11 layers (141 -> 144 TFLOP/s) and lose 13 % on the k = 3
-// layers at 128 channels (the register cap spills 156 B / lane): left at 2.
-#ifndef E2ETTS_F32_OCC
-#define E2ETTS_F32_OCC 2
-#endif
-template <int BM, int BN, int MODE, bool BFRAG, int CPI>
-constexpr int conv_min_waves() { return (MODE == 0 && BFRAG && CPI == 0 && BM * BN <= 128 * 128) ? E2ETTS_F32_OCC : 2; }
-
-template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0>
-__global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block,
+// OCC: waves per SIMD the register allocation must allow.  The exact-fp32 128 x 128 kernel on fragment-order weights keeps only its
+// slab in LDS (<= 28 KB), so a third workgroup fits on the CU if the kernel stays within 168 VGPRs.  At OCC = 3 ("LEAN") the weight
+// fragments wait in a ring of two k-groups instead of four and the epilogue requests residual rows per 16-row half: no spill left in
+// the MFMA loop (36 B / lane outside it; with the full ring the cap spilled a float4 per k-group and lost 13 % on the k = 3 layers).
+// Same-box A/B on the headline step: k = 11 layers 139.5 -> 141.5 (128 channels) / 139.9 -> 143.7 (256) TFLOP/s, the FFN's k = 9
+// convolution 139 -> 142.8, k = 7 136 -> 140; the class 59.1 -> 58.6 ms/step.  The polyphase upsamplers (structural-zero taps skipped:
+// short, irregular iterations) LOSE 8-15 % at three waves, so launch_cfg keeps them -- and every other tile shape -- at OCC = 2.
+template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block,
                                                                                                       const int gx, const int ny) {
   constexpr bool K1 = CPI > 0;
   static_assert(!K1 || BFRAG, "multi-chunk items exist on the fragment path only");
@@ -129,6 +126,8 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
   constexpr int AROWS1 = K1 ? BM / 32 : (BM + MAX_HALO + 31) / 32;  // slab rows staged per thread and plane (upper bound)
   constexpr int AROWS = AROWS1 * (K1 ? CPI : 1);
   constexpr int ELD = WN + 4;                         // epilogue patch row stride (floats)
+  constexpr bool LEAN = OCC >= 3;
+  static_assert(!LEAN || (MODE == 0 && BFRAG && CPI == 0), "the three-wave form exists for the exact-fp32 fragment path");
   static_assert(4 * 16 * ELD <= BM * LDK, "epilogue patches must fit in the slab");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -214,15 +213,16 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
   constexpr int KS = X3 ? BK / 16 : BK / 8;  // k-steps per 32-channel chunk: 2 x 16 (bf16 MFMA) or 4 x (4 MFMAs of k = 2) (fp32)
   constexpr int HL = X3 ? 2 : 1;
   float4 bfr[KS][NT][HL];  // [k-step][n tile][hi | lo] fragments of the CURRENT iteration (BFRAG)
-  auto load_frag = [&](int chunk, int j, int ks) {
+  auto load_frag_to = [&](int slot, int chunk, int j, int ks) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int hl = 0; hl < HL; ++hl) {
         const int soff = ((((fnt[n] * p.KW + j) * nchunk + chunk) * KS + ks) * HL + hl) * 1024;
-        bfr[ks][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
+        bfr[slot][n][hl] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wf_rsrc, lane * 16, soff, 0));
       }
   };
+  auto load_frag = [&](int chunk, int j, int ks) { load_frag_to(ks, chunk, j, ks); };
   int wvoff[BROWS];
   bool wok[BROWS];
   bool w_all_ok = true;
@@ -356,28 +356,25 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
     float* patch = As + wave * (16 * ELD);  // wave-private: no workgroup barrier between its write and read
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      float4 resv[2][PASSES];  // residual rows of this 32-row block, requested before its transposes
-      if constexpr (RES) {
+      // LEAN (the instantiations compiled for three waves per SIMD, 168 registers): residual / accumulate rows are requested per
+      // 16-row half, right before that half's transposes, instead of both halves up front -- half the registers, less cover
+      float4 resv[LEAN ? 1 : 2][PASSES];  // residual rows of this 32-row block, requested before its transposes
+      float4 accv[LEAN ? 1 : 2][PASSES];  // accumulate mode: what the output rows hold now, requested together with the residual
+      auto request_rows = [&](int hh) __attribute__((always_inline)) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) {
-            const int t = min(t0 + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
-            resv[hh][ps] = *reinterpret_cast<const float4*>(res_b + (long long)t * p.res_ld + ecol_c);
-          }
-      }
-      float4 accv[2][PASSES];  // accumulate mode: what the output rows hold now, requested together with the residual
-      if constexpr (ACC) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) {
-            const int t = min(t0 + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
-            accv[hh][ps] = *reinterpret_cast<const float4*>(out_b + (long long)t * p.out_ld + ecol_c);
-          }
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int t = min(t0 + m * 32 + hh * 16 + ps * RPP + prow, p.T - 1);
+          if constexpr (RES) resv[LEAN ? 0 : hh][ps] = *reinterpret_cast<const float4*>(res_b + (long long)t * p.res_ld + ecol_c);
+          if constexpr (ACC) accv[LEAN ? 0 : hh][ps] = *reinterpret_cast<const float4*>(out_b + (long long)t * p.out_ld + ecol_c);
+        }
+      };
+      if constexpr (!LEAN) {
+        request_rows(0);
+        request_rows(1);
       }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
+        if constexpr (LEAN) request_rows(hh);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -400,14 +397,14 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
             v.z *= 1.0f / (1.0f + expf(-v.z)); v.w *= 1.0f / (1.0f + expf(-v.w));
           }
           if constexpr (RES) {
-            const float4 rv = resv[hh][ps];
+            const float4 rv = resv[LEAN ? 0 : hh][ps];
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
           }
           if (t >= len) v = make_float4(0.f, 0.f, 0.f, 0.f);
           const bool ok = t < p.T && ecol_ok;
           float4* o = reinterpret_cast<float4*>(out_b + (long long)min(t, p.T - 1) * p.out_ld + ecol_c);
           if constexpr (ACC) {
-            const float4 ov = accv[hh][ps];
+            const float4 ov = accv[LEAN ? 0 : hh][ps];
             v.x += ov.x; v.y += ov.y; v.z += ov.z; v.w += ov.w;
           }
           if (ACC && p.out_div != 1.0f) {
@@ -459,7 +456,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
   store_a();
   if constexpr (BFRAG) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) load_frag(0, 0, ks);
+    for (int ks = 0; ks < (LEAN ? 2 : KS); ++ks) load_frag(0, 0, ks);  // LEAN: a ring of two k-groups (see the fp32 MFMA block)
     // hipcc may issue these in any order; whatever is still in flight at the loop head would force the head's wait for
     // the first fragment down to vmcnt(0) in EVERY iteration.  Drained here, the wait inside the loop stays counted.
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -548,7 +545,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
         for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(a_base + m * 32 * LDK + q * 8);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          if constexpr (BFRAG) bf[n] = bfr[q][n][0];
+          if constexpr (BFRAG) bf[n] = bfr[LEAN ? (q & 1) : q][n][0];
           else bf[n] = *reinterpret_cast<const float4*>(b_base + n * 32 * LDK + q * 8);
         }
 #pragma unroll
@@ -561,7 +558,17 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
           }
         }
-        if constexpr (BFRAG) {  // as in the bf16 branch: this k-step's fragments for the NEXT iteration, unconditionally
+        if constexpr (BFRAG && LEAN) {
+          // three waves per SIMD (168 registers): the fragments wait in a ring of TWO k-groups instead of a whole iteration's four --
+          // 16 registers less, and two k-groups (32 MFMAs, 2 048 cycles) are still several L2 round trips of cover.  Slot q & 1 is
+          // consumed: it takes k-group q + 2 of this iteration, or k-group q - 2 of the next one.
+          if (q < 2) {
+            load_frag_to(q & 1, chunk, j, q + 2);
+          } else {
+            if (!last_tap) load_frag_to(q & 1, chunk, j + 1, q - 2);
+            else load_frag_to(q & 1, nchk, 0, q - 2);
+          }
+        } else if constexpr (BFRAG) {  // as in the bf16 branch: this k-step's fragments for the NEXT iteration, unconditionally
           if constexpr (K1) {
             load_frag(last_tap ? nchk * CPI : chunk * CPI + j + 1, 0, q);
           } else {
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(256, (conv_min_waves<BM, BN, MODE, BFRAG, CPI>())) 
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0>
+template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0, int OCC = 2>
 const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   const int halo = p.dil * (p.KW - 1);
   static const int lds_pad = getenv("E2ETTS_LDS_PAD") ? atoi(getenv("E2ETTS_LDS_PAD")) : 0;  // tuning aid: occupancy experiments
@@ -611,7 +618,7 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   if (lds > 80 * 1024) return "conv_gemm: LDS tile exceeds 80 KiB";
   if (lds > 64 * 1024) {  // the multi-chunk Linear form: opt in once per instantiation (two workgroups per CU still fit)
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (attr != hipSuccess) return "conv_gemm: cannot raise the dynamic LDS limit";
   }
   const int mtiles = (p.T + BM - 1) / BM;
@@ -628,7 +635,7 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   const long long groups8 = ((long long)gx * p.B + 7) / 8;        // row groups per XCD
   if (groups8 * 8 * ntiles >= (1LL << 31)) return "conv_gemm: grid too large";
   dim3 grid((unsigned)(groups8 * 8 * ntiles));
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI>), grid, dim3(256), lds, s, p, tpb, gx, ntiles);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI, OCC>), grid, dim3(256), lds, s, p, tpb, gx, ntiles);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
 }
 
@@ -652,6 +659,12 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
         if (cpi_env >= 4 && p.Cin % (4 * BK) == 0) return launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, true, 4>(p, s);
         if (p.Cin % (2 * BK) == 0) return launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, true, 2>(p, s);
       }
+    }
+    if constexpr (MODE == 0 && BM == 128 && BN == 128) {  // three waves per SIMD (see OCC above); E2ETTS_F32_OCC=2: off (tuning aid)
+      static const bool occ3 = !(getenv("E2ETTS_F32_OCC") && atoi(getenv("E2ETTS_F32_OCC")) == 2);
+      if (p.wfrag && occ3 && p.zero_tap_split == 0)
+        return p.accumulate ? launch_cfg_impl<BM, BN, WM, WN, MODE, true, true, true, 0, 3>(p, s)
+                            : launch_cfg_impl<BM, BN, WM, WN, MODE, false, true, true, 0, 3>(p, s);
     }
     if (p.wfrag)
       return p.accumulate ? launch_cfg_impl<BM, BN, WM, WN, MODE, true, true, true>(p, s)

@@ -623,11 +623,13 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   }
   const int mtiles = (p.T + BM - 1) / BM;
   const int ntiles = (p.Cout + BN - 1) / BN;
-  // Persistent over M: enough workgroups for ~8 per CU, each walking up to 8 consecutive tiles.
+  // Persistent over M: enough workgroups for ~24 per CU, each walking consecutive tiles of one utterance.
   // (ragged batches: the tiles that will really run -- sized on the padded total the row groups came out too long and too few, and the
-  // last round of workgroups ran a third empty: 110-118 instead of 137-140 TFLOP/s on the mixed-length batch)
+  // last round of workgroups ran a third empty: 110-118 instead of 137-140 TFLOP/s on the mixed-length batch.  24 rather than the
+  // earlier 8 for the same reason: a mixed-length batch ends every utterance in a partial group, and with 2-3 workgroups resident per
+  // CU eight groups per CU are only three or four rounds -- 140.5 -> 135.4 ms/step on BASELINE config 3, the fixed-length batch unchanged)
   const long long total = (long long)((double)mtiles * ntiles * p.B * (p.act_frac > 0.0 && p.act_frac <= 1.0 ? p.act_frac : 1.0));
-  static const int wg_per_cu = getenv("E2ETTS_WG_PER_CU") ? atoi(getenv("E2ETTS_WG_PER_CU")) : 8;  // tuning aid
+  static const int wg_per_cu = getenv("E2ETTS_WG_PER_CU") ? atoi(getenv("E2ETTS_WG_PER_CU")) : 24;  // tuning aid
   int tpb = (int)(total / (256 * wg_per_cu));
   tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
   if (tpb > mtiles) tpb = mtiles;

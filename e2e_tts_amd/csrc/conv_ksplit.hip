@@ -1,18 +1,21 @@
-// conv_ksplit: "same" 1-D convolution / Linear in exact fp32 for the PHONEME-LEVEL layers -- the encoder's FFT blocks (reference
-// U/blocks/transformer.py:213-240, 289-297) and the duration / pitch / energy predictors (U/layers.py:410-420, 491-505) -- with the K
-// dimension split four ways INSIDE the workgroup.
+// conv_ksplit.hip -- the convolutions of the LATENCY path: one kernel, conv_rows_kernel, in which every wavefront owns its output tile,
+// its slab rows (private, double-buffered LDS) and a ring of weight fragments, and no workgroup barrier exists.  Two uses:
 //
-// Why a second convolution kernel.  These layers see B x L phonemes, not B x T frames: 128 rows at B = 1, 4 096 at B = 32 -- 1.3 % of the
-// step's FLOPs -- but each output tile sums over K = KW x Cin up to 3 456 (the FFN's k = 9 convolution), and in conv_gemm.hip one wave
-// walks that whole K as ONE chain of dependent v_mfma_f32_32x32x2_f32: 1 728 MFMAs x 64 cycles = 46 us per launch however few rows there
-// are, 30 such launches per step.  Here the four waves of a workgroup share ONE 32 x 32 (or 32 x 64) output tile and take the 32-channel
-// chunks of Cin round-robin (wave w: chunks w, w + 4, ...), each with its own slab rows in a private piece of LDS and its own weight
-// fragments from L2 (launch_f32_to_frag's order): no workgroup barrier until the end, a chain a quarter as long, four times the waves.
-// The partial sums meet in LDS and are added in a FIXED order, ((P0 + P1) + (P2 + P3)), before bias / activation / residual.
-//
-// That order differs from conv_gemm's single chain, so this kernel serves these layers at EVERY batch size: an utterance's durations,
+// (1) launch_conv_ksplit (SPLITK): "same" 1-D convolution / Linear in exact fp32 for the PHONEME-LEVEL layers -- the encoder's FFN
+// convolutions (reference U/blocks/transformer.py:289-297) and the duration / pitch / energy predictors (U/layers.py:410-420, 491-505)
+// -- with the K dimension split four ways INSIDE the workgroup.
+//   These layers see B x L phonemes, not B x T frames: 128 rows at B = 1, 4 096 at B = 32 -- 1.3 % of the step's FLOPs -- but each
+// output tile sums over K = KW x Cin up to 3 456 (the FFN's k = 9 convolution), and in conv_gemm.hip one wave walks that whole K as ONE
+// chain of dependent v_mfma_f32_32x32x2_f32: 1 728 MFMAs x 64 cycles = 46 us per launch however few rows there are.  Here the four waves
+// of a workgroup share ONE 32 x 32 (or 32 x 64) output tile and take the 32-channel chunks of Cin round-robin (wave w: chunks w, w + 4,
+// ...): a chain a quarter as long, four times the waves.  The partial sums meet in LDS and are added in a FIXED order,
+// ((P0 + P1) + (P2 + P3)), before bias / activation / residual.
+//   That order differs from conv_gemm's single chain, so this form serves these layers at EVERY batch size: an utterance's durations,
 // pitch and energy buckets and encoder output do not depend on what it is batched with (tests/test_gpu_parity.py: B = 1 against the
 // same utterance inside B = 32, bit for bit), and the discrete outputs keep matching the reference on every fixture.
+//
+// (2) launch_conv_rows: conv_gemm's OWN arithmetic, MFMA for MFMA, for launches with few rows (the decoder and postnet convolutions of
+// the B = 1 path) -- see the comment above the kernel.  Same bits as conv_gemm, so the engine picks per launch.
 #include <type_traits>
 #include <utility>
 

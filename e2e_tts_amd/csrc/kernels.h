@@ -90,6 +90,8 @@ const char* launch_length_regulate(const float* x, const int32_t* cum, const int
                                    float* y, int B, int L, int T, int H, hipStream_t s);
 // out[b] = min(cap, (lens[b] + add) * mul): rows a layer has to compute for utterance b in ragged mode
 const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s);
+// S = (S + Sj) [/ div] over n floats (n % 4 == 0): joins the sums of ResBlocks run on side streams
+const char* launch_accum_div(float* S, const float* Sj, long long n, float div, hipStream_t s);
 // [B, C, T] -> [B, T, C]
 // One (conv k, dilation d -> leaky ReLU -> conv k, dilation 1 -> + x) pair of a HiFi-GAN ResBlock1 in one launch
 // (resblock_pair.hip): out = c2(lrelu(c1(lrelu(x)) + b1)) + b2 + x, optionally (out_old + that) / out_div.

@@ -655,6 +655,25 @@ const char* launch_length_regulate(const float* x, const int32_t* cum, const int
   return CHECK_LAUNCH("length_regulate");
 }
 
+// S = (S + Sj) [/ div]: joins the stage sums of ResBlocks that ran side by side (engine.hip, small batches); the operations the
+// accumulating epilogues of conv_gemm / resblock_pair / resblock_chain perform, in their order.
+__global__ void accum_div_kernel(float* __restrict__ S, const float* __restrict__ Sj, long long n4, float div) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = reinterpret_cast<const float4*>(S)[i];
+  const float4 b = reinterpret_cast<const float4*>(Sj)[i];
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  if (div != 1.0f) { a.x = a.x / div; a.y = a.y / div; a.z = a.z / div; a.w = a.w / div; }
+  reinterpret_cast<float4*>(S)[i] = a;
+}
+
+const char* launch_accum_div(float* S, const float* Sj, long long n, float div, hipStream_t s) {
+  if (!S || !Sj || n <= 0 || (n & 3)) return "accum_div: bad arguments";
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(accum_div_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, S, Sj, n4, div);
+  return hipGetLastError() == hipSuccess ? nullptr : "accum_div: launch failed";
+}
+
 const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s) {
   if (!lens || !out || B <= 0) return "act_rows: bad arguments";
   hipLaunchKernelGGL(act_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lens, out, B, add, mul, cap);

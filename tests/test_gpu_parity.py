@@ -762,7 +762,9 @@ def test_attention_split_form_is_bit_identical_to_one_wavefront_per_query_tile(t
     which adds its two half sums in the same order.  The child process is held to the one-wavefront kernels (E2ETTS_ATT_SPLIT_MAX=0, read
     once per process): durations, buckets and mel must come out bit for bit the same as from this process's split kernels.  The child
     also runs its few-rows convolutions on conv_gemm's 64 x 64 tile (E2ETTS_ROWS=0) where this process takes conv_rows -- one wavefront
-    per 32-row tile, no workgroup barrier, the same MFMA sequence."""
+    per 32-row tile, no workgroup barrier, the same MFMA sequence -- and its vocoder's ResBlocks one after the other on one stream
+    (E2ETTS_VOC_CONC_FRAMES=0) where this process runs the three of a stage side by side on HIP side streams and joins their sums:
+    waveform and PCM bit for bit as well."""
     import os
     import subprocess
     import sys
@@ -774,6 +776,7 @@ def test_attention_split_form_is_bit_identical_to_one_wavefront_per_query_tile(t
     d, p, e = (float(x) for x in g["controls"])
     r = eng.acoustic(g["ids"], g["lens"], spk, d, p, e, want=("dur", "mel_lens", "pitch_idx", "energy_idx"))
     mel, mel_post = eng.fetch_mel(r["B"], r["T"])
+    wav, pcm = eng.vocoder(None, r["B"], r["T"], pcm=True)
     eng.set_precision("fp32")
     script = tmp_path / "att_child.py"
     script.write_text(
@@ -788,9 +791,10 @@ def test_attention_split_form_is_bit_identical_to_one_wavefront_per_query_tile(t
         "spk = np.array([int(g['speaker'])], np.int64); d, p, e = (float(x) for x in g['controls'])\n"
         "r = eng.acoustic(g['ids'], g['lens'], spk, d, p, e, want=('dur', 'mel_lens', 'pitch_idx', 'energy_idx'))\n"
         "mel, mel_post = eng.fetch_mel(r['B'], r['T'])\n"
-        "np.savez(sys.argv[1], mel=mel, mel_post=mel_post, dur=r['dur'], pitch_idx=r['pitch_idx'], energy_idx=r['energy_idx'])\n")
+        "wav, pcm = eng.vocoder(None, r['B'], r['T'], pcm=True)\n"
+        "np.savez(sys.argv[1], mel=mel, mel_post=mel_post, dur=r['dur'], pitch_idx=r['pitch_idx'], energy_idx=r['energy_idx'], wav=wav, pcm=pcm)\n")
     out = tmp_path / "att.npz"
-    env = dict(os.environ, E2ETTS_ATT_SPLIT_MAX="0", E2ETTS_ROWS="0")
+    env = dict(os.environ, E2ETTS_ATT_SPLIT_MAX="0", E2ETTS_ROWS="0", E2ETTS_VOC_CONC_FRAMES="0")
     rr = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=900)
     assert rr.returncode == 0, rr.stderr[-3000:]
     o = np.load(out)
@@ -798,6 +802,8 @@ def test_attention_split_form_is_bit_identical_to_one_wavefront_per_query_tile(t
         np.testing.assert_array_equal(o[k], r[k])
     np.testing.assert_array_equal(o["mel"], mel)
     np.testing.assert_array_equal(o["mel_post"], mel_post)
+    np.testing.assert_array_equal(o["wav"], wav)
+    np.testing.assert_array_equal(o["pcm"], pcm)
     assert np.abs(mel).max() > 0.1
 
 

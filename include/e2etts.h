@@ -18,7 +18,9 @@
  *    a buffer handed in as an output): call e2etts_order_after(engine, that_stream) first -- the engine's stream
  *    then waits for everything queued on that stream so far -- or synchronise that stream yourself.  The Python
  *    binding does this for every torch CUDA tensor argument (torch.cuda.current_stream());
- *  - one engine = one GPU + one HIP stream; calls on one engine are serialised by an internal mutex;
+ *  - one engine = one GPU + one HIP stream (at small batches the vocoder forks the ResBlocks of a stage onto internal side
+ *    streams and joins them back into that stream before anything else reads their sum: invisible to the caller, same
+ *    results bit for bit); calls on one engine are serialised by an internal mutex;
  *    distinct engines are independent (one process per GPU in multi-GPU runs);
  *  - all activations are fp32, channels-last ([B, N, C]); weights come packed by
  *    e2e_tts_amd/packer.py (weight-norm and BatchNorm folded, conv weights tap-major).

@@ -1033,8 +1033,11 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   // ResBlock's launches -- 384 tiles on 256 CUs at B = 1, chains of 40-70 us kernels -- leave CUs idle at every tail.  They run side by
   // side: ResBlock 0 on the engine's stream into S, ResBlock j > 0 on a side stream into a sum buffer of its own, joined by
   // S = (S + S_j) [/ num_kernels] in the accumulating epilogue's order -- same operations, same bits.  Off while the full class profile is taken
-  // and above E2ETTS_VOC_CONC_FRAMES frames (default 2 048), where every launch fills the chip.
-  static const long long conc_frames = getenv("E2ETTS_VOC_CONC_FRAMES") ? atoll(getenv("E2ETTS_VOC_CONC_FRAMES")) : 2048;
+  // and above E2ETTS_VOC_CONC_FRAMES frames (default 2 048; 4 096 in exact fp32), where every launch fills the chip.
+  // (measured per batch size and mode: bf16x3 gains up to B = 2 at T = 768 and loses 1-2 % from B = 4, exact fp32 still gains 2 % at
+  // B = 4 and loses from B = 8; a per-stage limit on the tile count instead showed nothing beyond noise)
+  static const long long conc_env = getenv("E2ETTS_VOC_CONC_FRAMES") ? atoll(getenv("E2ETTS_VOC_CONC_FRAMES")) : -1;
+  const long long conc_frames = conc_env >= 0 ? conc_env : (e->voc_precision == E2ETTS_PRECISION_FP32 ? 4096 : 2048);
   const int nk = c.voc_n_kernels;
   // (a profile of ALL classes wants one kernel at a time; a profile filtered to one class -- bench.py's timed region -- records its
   // events on whichever stream the launch goes to and is fine)

@@ -7,7 +7,7 @@ int16 PCM on rank 0 (44 KB per audio-second).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -22,6 +22,14 @@ def shard_utterances(seq_lens: Sequence[int], world: int) -> List[List[int]]:
         rank = slot if rnd % 2 == 0 else world - 1 - slot
         shards[rank].append(idx)
     return shards
+
+
+def _world_rank() -> Tuple[int, int]:
+    """(world size, rank) of the default process group; (1, 0) when torch.distributed is not initialised (one GPU, no launcher)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
 
 
 def broadcast_blob(blob: Optional[np.ndarray], src: int = 0, device=None):
@@ -41,30 +49,78 @@ def broadcast_blob(blob: Optional[np.ndarray], src: int = 0, device=None):
     return t
 
 
-def gather_pcm(local: List[Tuple[int, np.ndarray]], dst: int = 0):
-    """Collect (utterance index, int16 PCM) pairs on rank `dst`; returns them sorted by index there, None elsewhere."""
+def gather_pcm(local: List[Tuple[int, np.ndarray]], dst: int = 0, device=None, stats: Optional[Dict] = None):
+    """Collect (utterance index, int16 PCM) pairs on rank `dst`; returns them sorted by index there, None elsewhere.
+
+    Tensor collectives only (no pickling of the payload): every rank sends ONE flat int16 tensor -- its PCM back to back, padded to the
+    longest rank's total -- plus a small (index, sample count) table, and `dst` slices views out of what it received.  `device`: where
+    the collectives run -- a cuda device under backend "nccl" (RCCL moves device memory: the PCM takes one H2D copy here, rides xGMI,
+    and `dst` brings all of it back with ONE D2H copy into page-locked memory), None / "cpu" under gloo.
+    `stats` (optional dict) receives `samples_per_rank` on `dst`."""
+    import torch
     import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
-    bucket = [None] * world if rank == dst else None
-    dist.gather_object(local, bucket, dst=dst)
+    world, rank = _world_rank()
+    if world == 1:
+        merged = sorted(local, key=lambda kv: kv[0])
+        if stats is not None:
+            stats["samples_per_rank"] = [int(sum(p.size for _, p in local))]
+        return merged
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    n_local = len(local)
+    total = int(sum(p.size for _, p in local))
+    head = torch.tensor([n_local, total], dtype=torch.int64, device=dev)
+    dist.all_reduce(head, op=dist.ReduceOp.MAX)                     # longest table, longest payload
+    max_n, max_total = int(head[0].item()), int(head[1].item())
+    table = torch.full((max(max_n, 1), 2), -1, dtype=torch.int64)
+    for k, (idx, pcm) in enumerate(local):
+        if pcm.dtype != np.int16 or pcm.ndim != 1:
+            raise TypeError("gather_pcm: PCM must be 1-D int16")
+        table[k, 0], table[k, 1] = int(idx), int(pcm.size)
+    tables = [torch.empty_like(table, device=dev) for _ in range(world)]
+    dist.all_gather(tables, table.to(dev))
+    flat = torch.zeros(max(max_total, 1), dtype=torch.int16)
+    if total:
+        flat[:total] = torch.from_numpy(np.concatenate([p for _, p in local]))
+    flat = flat.view(torch.uint8).to(dev)      # bytes on the wire: gloo has no int16 collectives
+    bucket = [torch.empty_like(flat) for _ in range(world)] if rank == dst else None
+    dist.gather(flat, bucket, dst=dst)
     if rank != dst:
         return None
-    merged = [item for part in bucket for item in part]
+    if dev.type == "cuda":   # one device-to-host copy of everything, into page-locked memory
+        host = torch.empty((world, flat.numel()), dtype=torch.uint8, pin_memory=True)
+        host.copy_(torch.stack(bucket), non_blocking=False)
+    else:
+        host = torch.stack(bucket)
+    host_np = host.view(torch.int16).numpy()
+    merged: List[Tuple[int, np.ndarray]] = []
+    per_rank = []
+    for r in range(world):
+        tb = tables[r].cpu().numpy()
+        off = 0
+        for idx, cnt in tb:
+            if idx < 0:
+                break
+            merged.append((int(idx), host_np[r, off:off + int(cnt)]))
+            off += int(cnt)
+        per_rank.append(off)
     merged.sort(key=lambda kv: kv[0])
+    if stats is not None:
+        stats["samples_per_rank"] = per_rank
     return merged
 
 
 def synthesize_sharded(engine, id_lists: Sequence[Sequence[int]], speaker: int = 0, batch_size: int = 32, hop_length: Optional[int] = None,
-                       controls: Tuple[float, float, float] = (1.0, 1.0, 1.0), dst: int = 0):
+                       controls: Tuple[float, float, float] = (1.0, 1.0, 1.0), dst: int = 0, device=None, stats: Optional[Dict] = None):
     """BASELINE config 4 end to end (256 utterances over 8 GPUs): every rank holds the SAME list of phoneme-id lists, takes its shard
     (`shard_utterances`), synthesises it in padded batches of `batch_size` (longest first, as `TTS.input_parse` sorts,
     reference API/utils.py:84) with its own engine, and rank `dst` receives the int16 PCM of every utterance in input order
-    (None elsewhere).  No collective on the data path: the only communication is the final gather of the PCM.
+    (None elsewhere).  No collective on the data path: the only communication is the final gather of the PCM (`gather_pcm`; `device`
+    as there).  Without an initialised process group it is the one-GPU form of the same loop (reference API/utils.py:130-151).
 
     `engine` is an `e2e_tts_amd._lib.Engine` (anything with `.synthesize(ids, lens, speaker, d, p, e) -> (pcm, mel_lens, T)` and
-    `.dims.hop_length`)."""
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
+    `.dims.hop_length`).  `stats` (optional dict) receives on `dst`: `samples_per_rank`, `balance_max_over_mean` (largest rank's valid
+    samples over the mean: 1.0 = perfectly even shards) and, on every rank, `batches` (this rank's batch count)."""
+    world, rank = _world_rank()
     hop = hop_length if hop_length is not None else engine.dims.hop_length
     lens_all = [len(x) for x in id_lists]
     if any(n <= 0 for n in lens_all):
@@ -72,6 +128,7 @@ def synthesize_sharded(engine, id_lists: Sequence[Sequence[int]], speaker: int =
     mine = shard_utterances(lens_all, world)[rank]          # already longest first
     spk = np.array([int(speaker)], np.int64)
     local: List[Tuple[int, np.ndarray]] = []
+    n_batches = 0
     for start in range(0, len(mine), batch_size):
         idx = mine[start:start + batch_size]
         lens = np.array([lens_all[i] for i in idx], np.int64)
@@ -79,10 +136,16 @@ def synthesize_sharded(engine, id_lists: Sequence[Sequence[int]], speaker: int =
         for b, i in enumerate(idx):
             ids[b, :lens[b]] = np.asarray(id_lists[i], np.int64)
         pcm, mel_lens, _ = engine.synthesize(ids, lens, spk, *controls)
+        n_batches += 1
         for b, i in enumerate(idx):
             local.append((i, np.array(pcm[b, :int(mel_lens[b]) * hop], copy=True)))
-    merged = gather_pcm(local, dst=dst)
+    if stats is not None:
+        stats["batches"] = n_batches
+    merged = gather_pcm(local, dst=dst, device=device, stats=stats)
     if merged is None:
         return None
     assert [k for k, _ in merged] == list(range(len(id_lists)))
+    if stats is not None and stats.get("samples_per_rank"):
+        spr = stats["samples_per_rank"]
+        stats["balance_max_over_mean"] = max(spr) / (sum(spr) / len(spr)) if sum(spr) else 1.0
     return [pcm for _, pcm in merged]

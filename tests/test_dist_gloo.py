@@ -144,3 +144,73 @@ def test_bench_multi_rank_branch_contract_world2():
     assert "cpu_baseline" not in d and "split_precision_mode" not in d   # N = 1 extras
     for k in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "roofline", "ms_per_step_median"):
         assert k in d, k
+
+
+def _run_bench_plainly(*args):
+    import json
+    import subprocess
+    env = dict(os.environ, E2ETTS_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout      # rank 0's line and nothing else on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_called_plainly_with_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher in the command.  The parent starts two fresh rank processes
+    before importing torch, relays rank 0's one JSON line and exits 0; the line carries the headline keys for n_gpus = 2 and the
+    config-4 record (256 utterances sharded over both ranks) beside them.  Stand-in engine, gloo: the harness, not a measurement."""
+    d = _run_bench_plainly("--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert d["data"] == "stub" and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 64 and d["collective_backend"] == "gloo" and d["rccl_ranks"] == 0
+    assert d["weight_bcast_ms"] > 0
+    c4 = d["c4_sharded"]
+    assert c4["utterances"] == 256 and c4["ranks"] == 2 and c4["scaling"] == "strong"
+    assert len(c4["frames_per_rank"]) == 2 and sum(c4["frames_per_rank"]) == 8 * 23040 // 6 * 6   # config 3's 3 840 phonemes x 8 x 6 frames
+    assert 1.0 <= c4["balance_max_over_mean"] <= 1.01 and c4["batches_per_rank"] == 4
+    assert "cpu_baseline" not in d and "c5_longform" not in d
+
+
+def test_bench_rank_failure_is_reported_by_the_launcher():
+    """A rank that dies takes the launcher's exit code with it, and no JSON line appears."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1")       # no stub: without a GPU every rank refuses to run
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "E2ETTS_BENCH_STUB"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "no CPU fallback" in r.stderr
+
+
+def test_bench_workload_c4_world2():
+    """`--workload c4` (BASELINE config 4) under gloo with two self-launched ranks and the stand-in engine: the sharded loop runs on
+    both ranks, rank 0 receives every utterance's PCM in input order (bench.py asserts order and exact lengths on the first pass), and
+    the line reports strong scaling over the whole job plus the per-rank balance."""
+    d = _run_bench_plainly("--gpus", "2", "--workload", "c4", "--utterances", "64", "--steps", "2", "--warmup", "1")
+    assert d["data"] == "stub" and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 64
+    c4 = d["c4_sharded"]
+    assert c4["utterances"] == 64 and c4["ranks"] == 2 and c4["batches_per_rank"] == 1
+    frames = 2 * 23040                                   # config 3's lengths twice, 6 frames per phoneme
+    assert sum(c4["frames_per_rank"]) == frames and max(c4["frames_per_rank"]) - min(c4["frames_per_rank"]) <= 6 * 200
+    assert 1.0 <= c4["balance_max_over_mean"] < 1.03
+    assert abs(d["value"] - frames * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6     # whole-job valid samples over the MAX-over-ranks time
+    assert "timed_region" in d["config"] and "rank 0" in d["config"]["timed_region"]
+
+
+def test_synthesize_sharded_without_a_process_group_is_the_one_gpu_loop():
+    rng = np.random.Generator(np.random.PCG64(3))
+    lists = [[int(k + 1)] + rng.integers(4, 131, size=int(n) - 1).tolist() for k, n in enumerate(rng.integers(1, 50, size=11))]
+    eng = _StubEngine()
+    st = {}
+    out = edist.synthesize_sharded(eng, lists, speaker=0, batch_size=4, stats=st)
+    assert len(out) == 11 and all((pcm == k + 1).all() and pcm.size == len(ids) * 12 for k, (pcm, ids) in enumerate(zip(out, lists)))
+    assert st["batches"] == 3 and st["balance_max_over_mean"] == 1.0 and st["samples_per_rank"] == [sum(len(x) for x in lists) * 12]

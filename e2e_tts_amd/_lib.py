@@ -78,7 +78,7 @@ def load_library() -> C.CDLL:
     lib.e2etts_vocoder_stream_fetch.restype = I
     lib.e2etts_vocoder_stream_fetch.argtypes = [P, P, P, SZ]
     lib.e2etts_tempo.restype = I
-    lib.e2etts_tempo.argtypes = [P, P, SZ, F, I, P, SZ, C.POINTER(SZ)]
+    lib.e2etts_tempo.argtypes = [P, P, SZ, C.c_double, I, P, SZ, C.POINTER(SZ)]
     lib.e2etts_set_precision.restype = I
     lib.e2etts_set_precision.argtypes = [P, I, I]
     lib.e2etts_set_ragged.restype = I

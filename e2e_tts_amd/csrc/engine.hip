@@ -1052,6 +1052,17 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     if (!e->ev_fork) HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   }
   hipStream_t const main_stream = e->stream;
+  // A failure between a stage's fork and its join must not leave ResBlocks queued on the side streams: the next call could overwrite
+  // XU or vside[*] -- or ensure() free them -- under work still in flight.  Whatever path leaves this function while
+  // `armed`, the side streams are drained first.
+  struct SideDrain {
+    e2etts_engine* e; int n; bool armed;
+    ~SideDrain() {
+      if (!armed) return;
+      for (int j = 0; j < n; ++j)
+        if (e->side[j]) (void)hipStreamSynchronize(e->side[j]);
+    }
+  } drain{e, conc ? nk - 1 : 0, false};
   ConvParams p;
   p.B = B; p.T = T; p.act_rows = act_stage[0]; p.act_frac = vf; p.in = mel_btc; setw(p, e->voc_pre); p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
   p.KW = 7; p.pad = 3;
@@ -1073,6 +1084,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     if (n > 0x7fffffffLL / 2) return e->fail(E2ETTS_EINVAL, "utterance too long");
     if (conc) {  // fork: the side streams may start once the upsampler's output (and everything before it) is complete
       HIPCHK(e, hipEventRecord(e->ev_fork, main_stream));
+      drain.armed = true;
       for (int j = 0; j + 1 < nk; ++j) HIPCHK(e, hipStreamWaitEvent(e->side[j], e->ev_fork, 0));
     }
     float* const S_main = S;
@@ -1185,6 +1197,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         HIPCHK(e, hipStreamWaitEvent(main_stream, e->ev_join[j - 1], 0));
         KCHK(e, launch_accum_div(S_main, ptr<float>(e->vside[j - 1][0]), (long long)B * n * co, j == nk - 1 ? (float)nk : 1.0f, main_stream));
       }
+      drain.armed = false;  // every side stream's work is now ordered before the main stream's next launch
     }
   }
   if (istft) {
@@ -1607,19 +1620,19 @@ int e2etts_vocoder_stream_fetch(e2etts_engine* e, float* wav_out, int16_t* pcm_o
   return E2ETTS_OK;
 }
 
-int e2etts_tempo(e2etts_engine* e, const int16_t* pcm_in, size_t n_in, float speed, int sample_rate, int16_t* pcm_out, size_t capacity,
+int e2etts_tempo(e2etts_engine* e, const int16_t* pcm_in, size_t n_in, double speed, int sample_rate, int16_t* pcm_out, size_t capacity,
                  size_t* n_out) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(e, hipSetDevice(e->device));
   if (!pcm_in || !n_out) return e->fail(E2ETTS_EINVAL, "pcm_in / n_out must not be NULL");
-  if (!(speed >= 0.25f && speed <= 4.0f)) return e->fail(E2ETTS_EINVAL, "speed must lie in [0.25, 4]");
-  if (sample_rate < 4000 || sample_rate > 192000) return e->fail(E2ETTS_EINVAL, "sample_rate out of range");
+  if (!(speed >= 0.25 && speed <= 4.0)) return e->fail(E2ETTS_EINVAL, "speed must lie in [0.25, 4]");
+  if (sample_rate < 4000 || sample_rate > 96000) return e->fail(E2ETTS_EINVAL, "sample_rate must lie in [4000, 96000]");
   if (n_in == 0 || n_in > (size_t)1 << 30) return e->fail(E2ETTS_EINVAL, "n_in out of range");
   // the geometry of e2e_tts_amd/api.py: time_stretch_wsola: 40 ms frames (even), 50 % overlap, +-10 ms search
   const int n = std::max((int)(sample_rate * 40.0 / 1000.0) / 2 * 2, 64);
   const int hop_out = n / 2, delta = std::max((int)(sample_rate * 10.0 / 1000.0), 1);
-  const double sp = (double)speed;
+  const double sp = speed;
   const int n_frames = std::max((int)std::ceil(((double)n_in / sp) / hop_out), 1);
   const long long want = std::llrint((double)n_in / sp);   // Python round(): half to even
   const long long avail = (long long)n_frames * hop_out + hop_out;   // what the frames cover; want <= n_frames * hop_out + 1 by the choice of n_frames
@@ -1630,7 +1643,7 @@ int e2etts_tempo(e2etts_engine* e, const int16_t* pcm_in, size_t n_in, float spe
   RET(ensure(e, e->tempo_in, n_in * 2));
   RET(ensure(e, e->tempo_out, (size_t)std::max<long long>(nout, 1) * 2));
   RET(copy_in(e, e->tempo_in.p, pcm_in, n_in * 2));
-  if (speed == 1.0f) {
+  if (speed == 1.0) {
     RET(copy_out(e, pcm_out, e->tempo_in.p, n_in * 2));
   } else {
     KCHK(e, launch_wsola(ptr<int16_t>(e->tempo_in), (long long)n_in, ptr<int16_t>(e->tempo_out), nout, sp, n, delta, n_frames, e->stream));

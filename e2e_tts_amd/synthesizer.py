@@ -40,7 +40,9 @@ class _LazyCoqui:
 
 class Synthesizer:
     def __init__(self, output_dir: str = "outputs", acoustic_path: str = "e2e_tts/exps/acoustic/statedict.pt",
-                 vocoder_path: str = "e2e_tts/exps/vocoder/statedict.pt", **tts_kwargs) -> None:
+                 vocoder_path: str = "e2e_tts/exps/vocoder/statedict.pt", use_returned_path: bool = False, **tts_kwargs) -> None:
+        # use_returned_path: see synthesis().  False (default) = the reference's behaviour, path for path.
+        self.use_returned_path = bool(use_returned_path)
         vie_model = SynthesizerVN(acoustic_path=acoustic_path, vocoder_path=vocoder_path, output_dir=output_dir, **tts_kwargs)
         self.model_dict = {
             "eng": _LazyCoqui("tts_models/en/ljspeech/vits"),
@@ -64,10 +66,12 @@ class Synthesizer:
             speed = float(speed)
         language = language.split()[0]  # "<code> <Name>" (synthesizer.py:43)
         tts_output_filepath = os.path.join(self.output_dir, gen_filename())
-        # the path tts_to_file reports is the one that carries the requested tempo (<file>_<speed>.wav when speed != 1); the reference
-        # ignores it (synthesizer.py:47) and so hands the un-sped file on -- a defect the drop-in does not keep
+        # The reference ignores what tts_to_file returns (synthesizer.py:47) and hands on the path it passed in -- for speed != 1 that is
+        # NOT the file named <file>_<speed>.wav.  Kept as is by default (a drop-in returns what the reference returns; with the service's
+        # default speed_mode="duration" that file already carries the tempo, api.Synthesizer.synthesis).  use_returned_path=True opts
+        # into the path tts_to_file reports instead ("Behaviour the drop-in keeps").
         made = self.model_dict[language].tts_to_file(text, file_path=tts_output_filepath, speed=speed)
-        if isinstance(made, str) and os.path.exists(made):
+        if getattr(self, "use_returned_path", False) and isinstance(made, str) and os.path.exists(made):
             tts_output_filepath = made
         vc_output_filepath = None
         if target_filepath:

@@ -168,7 +168,10 @@ int e2etts_vocoder_stream_fetch(e2etts_engine* engine, float* wav_out, int16_t* 
  * reference; it mirrors e2e_tts_amd/api.py: time_stretch_wsola (40 ms frames, 50 % overlap, +-10 ms search, float64) step for step.
  * n_out receives round(n_in / speed); with pcm_out == NULL the call only reports that size.  speed in [0.25, 4].  (The Python mirror's
  * DEFAULT for speed != 1 is the model's own duration control -- no post-processing at all; this entry serves speed_mode="wsola".) */
-int e2etts_tempo(e2etts_engine* engine, const int16_t* pcm_in, size_t n_in, float speed, int sample_rate, int16_t* pcm_out,
+/* `speed` is a double: n_out and the per-frame analysis positions are computed from it exactly as the Python mirror computes them from
+ * its float (a C float 0.8f is 0.800000012, which rounds n_in / speed the other way at exact .5 ties).  sample_rate in [4000, 96000]: the
+ * kernel keeps one analysis frame, its search region and three work frames in LDS (0.18 s of float64 samples <= 160 KB). */
+int e2etts_tempo(e2etts_engine* engine, const int16_t* pcm_in, size_t n_in, double speed, int sample_rate, int16_t* pcm_out,
                  size_t capacity, size_t* n_out);
 
 /* Arithmetic of the convolutions / projections of (a) the vocoder and (b) the decoder + mel_linear + postnet.

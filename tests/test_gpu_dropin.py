@@ -300,8 +300,18 @@ def test_gpu_tempo_kernel_follows_the_host_wsola():
         assert same.mean() >= 0.98, (speed, same.mean())
         spec = np.abs(np.fft.rfft(got.astype(np.float64) * np.hanning(got.size)))
         assert abs(np.fft.rfftfreq(got.size, 1 / sr)[int(np.argmax(spec))] - 220.0) < 2.0   # pitch stays
+    # the C entry takes the speed as a double, so an exact .5 tie of n_in / speed rounds as Python's round() does
+    # (len % 8 == 6 at speed 0.8: n_in / 0.8 = k + 0.5; the float 0.8f = 0.800000012 would land just under it)
+    x6 = x[:x.size - ((x.size - 6) % 8)]
+    assert x6.size % 8 == 6 and (x6.size / 0.8) % 1 == 0.5
+    got = eng.tempo(x6, 0.8, sr)
+    ref = np.clip(np.rint(time_stretch_wsola(x6.astype(np.float64), 0.8, sr)), -32768, 32767).astype(np.int16)
+    assert got.shape == ref.shape == (round(x6.size / 0.8),)
+    assert (np.abs(got.astype(np.int32) - ref.astype(np.int32)) <= 1).mean() >= 0.98
     with pytest.raises(ValueError):
         eng.tempo(x, 8.0, sr)
+    with pytest.raises(ValueError, match="sample_rate"):
+        eng.tempo(x, 1.5, 192000)
     with pytest.raises(TypeError):
         eng.tempo(x.astype(np.float32), 1.5, sr)
     eng.close()

@@ -187,9 +187,10 @@ def test_wsola_time_stretch_and_wav_io(tmp_path):
     assert read_wav(out)[0].size == round(x.size / 1.5)
 
 
-def test_speed_paths_exist_and_facade_uses_the_returned_one(tmp_path):
+def test_speed_paths_exist_and_facade_keeps_the_reference_path_by_default(tmp_path):
     """Synthesizer.synthesis with speed != 1 (reference API/inference.py:44-49 writes the file, THEN derives <file>_<speed>.wav from
-    it): both paths exist afterwards, the returned one carries the tempo, and the top-level facade hands the returned path on."""
+    it): both paths exist afterwards, the returned one carries the tempo; the top-level facade hands on the path IT generated, as the
+    reference does, or the returned one with use_returned_path=True."""
     from e2e_tts_amd import api, synthesizer as top
 
     class StubTTS:  # stands in for the engine-backed TTS: the file handling is what is under test
@@ -215,8 +216,16 @@ def test_speed_paths_exist_and_facade_uses_the_returned_one(tmp_path):
     f = top.Synthesizer.__new__(top.Synthesizer)
     f.output_dir = str(tmp_path)
     f.model_dict = {"vie": s}
+    # default: the reference's own behaviour (synthesizer.py:47 ignores tts_to_file's return value): the path it generated comes back
     path, vc = f.synthesis("xin chao", "vie Vietnamese", speed=1.5)
-    assert vc is None and path.endswith("_1.5.wav") and os.path.exists(path)
+    assert vc is None and not path.endswith("_1.5.wav") and os.path.exists(path)
+    sped = path[:-4] + "_1.5.wav"
+    assert os.path.exists(sped)                                  # the service wrote it next to it, as the reference does
+    np.testing.assert_array_equal(api.read_wav(path)[0], api.read_wav(sped)[0])   # duration mode: both carry the tempo
+    # opt-in: hand on the path tts_to_file reports
+    f.use_returned_path = True
+    path, vc = f.synthesis("xin chao", "vie Vietnamese", speed=1.25)
+    assert vc is None and path.endswith("_1.25.wav") and os.path.exists(path)
     path, _ = f.synthesis("xin chao", "vie Vietnamese", speed=1.0)
     assert os.path.exists(path) and not path.endswith("_1.0.wav")
 

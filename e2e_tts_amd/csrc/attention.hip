@@ -11,6 +11,8 @@
 //   - the probabilities are already the B operand of O^T += V^T . P^T: register r of lane half h holds key
 //     k0(r) + 4h, k0(r) = (r & 3) + 8 (r >> 2), and MFMA step r consumes exactly the key pair {k0(r), k0(r) + 4}.
 #include <math.h>
+
+#include <algorithm>
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -29,9 +31,26 @@ namespace {
 // request was issued early to hide.  LDS writes and reads are counted by lgkmcnt alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// (utterance b, head, query block qblk) of this workgroup.  Padded grid: (x, y, z) = (query block, head, utterance).  Compact grid of a
+// ragged batch whose lengths the host knows (kernels.h: RowMap): 1-D, utterance b owns ceil(len_b / rows) x n_head consecutive blocks,
+// heads fastest -- no block of padded queries exists (their output rows keep what they held: every consumer masks them, engine.hip).
+#define ATT_BLOCK_OF_GRID(rows)                                    \
+  int b, head, qblk;                                               \
+  if (rm.n > 0) {                                                  \
+    int u_;                                                        \
+    if (!rowmap_find(rm, (int)blockIdx.x, b, u_)) return;          \
+    const int nh_ = H / DK;                                        \
+    head = u_ % nh_;                                               \
+    qblk = u_ / nh_;                                               \
+  } else {                                                         \
+    b = blockIdx.z;                                                \
+    head = blockIdx.y;                                             \
+    qblk = blockIdx.x;                                             \
+  }
+
 template <int DK>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                        const int32_t* __restrict__ lens, int N, int H, float temperature) {
+                                                        const int32_t* __restrict__ lens, int N, int H, float temperature, const RowMap rm) {
   constexpr int LDS_LD = DK + 4;
   constexpr int DT = DK / 32;  // 32-wide tiles of the head dimension
   constexpr int QQ = DK / 8;   // float4 fragments per query row and lane half
@@ -41,12 +60,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  ATT_BLOCK_OF_GRID(128)
+  const int q0 = qblk * 128 + wave * 32;
   const int len = min(lens ? lens[b] : N, N);
-  if (blockIdx.x * 128 >= len) {  // a tile of padded queries only: their rows are zero (ragged batches)
+  if (qblk * 128 >= len) {  // a tile of padded queries only: their rows are zero (padded grids; a compact grid has no such block)
     for (int i = tid; i < 128 * (DK / 4); i += 256) {
-      const int q = blockIdx.x * 128 + i / (DK / 4);
+      const int q = qblk * 128 + i / (DK / 4);
       if (q < N) *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + (i % (DK / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 // request the next chunk's K / V rows before this chunk's arithmetic (the staging round trip was exposed once per chunk).
 template <int DK, int QT>
 __global__ __launch_bounds__(QT * 128, 2) void attention_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                 const int32_t* __restrict__ lens, int N, int H, float temperature) {
+                                                                 const int32_t* __restrict__ lens, int N, int H, float temperature, const RowMap rm) {
   constexpr int LDS_LD = DK + 4;
   constexpr int DH = DK / 2;    // head-dim channels per wavefront
   constexpr int DTH = DH / 32;  // its 32-wide tiles
@@ -199,12 +218,12 @@ __global__ __launch_bounds__(QT * 128, 2) void attention_split_kernel(const floa
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int qt = wave >> 1, part = wave & 1;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * (QT * 32) + qt * 32;
+  ATT_BLOCK_OF_GRID(QT * 32)
+  const int q0 = qblk * (QT * 32) + qt * 32;
   const int len = min(lens ? lens[b] : N, N);
-  if (blockIdx.x * (QT * 32) >= len) {  // a tile of padded queries only: their rows are zero (ragged batches)
+  if (qblk * (QT * 32) >= len) {  // a tile of padded queries only: their rows are zero (padded grids)
     for (int i = tid; i < QT * 32 * (DK / 4); i += NTH) {
-      const int q = blockIdx.x * (QT * 32) + i / (DK / 4);
+      const int q = qblk * (QT * 32) + i / (DK / 4);
       if (q < N) *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + (i % (DK / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
@@ -520,7 +539,7 @@ __device__ __forceinline__ void split8(const float* v, bf16x8_t& hi, bf16x8_t& l
 // traffic, not arithmetic, is what the staging costs: 8 waves = 256 queries per workgroup halve it against 4.
 template <int DK, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                           const int32_t* __restrict__ lens, int N, int H, float temperature) {
+                                                           const int32_t* __restrict__ lens, int N, int H, float temperature, const RowMap rm) {
   constexpr int KS = DK + 4;   // words per K row: DK/2 (hi bf16) + DK/2 (lo bf16) + 4 pad; KS mod 64 == 4 -> conflict-free b128
   constexpr int VS = 36;       // words per Vt row: 16 (32 hi slots) + 16 (32 lo slots) + 4 pad
   constexpr int DT = DK / 32;  // 32-wide tiles of the head dimension
@@ -532,12 +551,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(const float* _
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  ATT_BLOCK_OF_GRID(NW * 32)
+  const int q0 = qblk * (NW * 32) + wave * 32;
   const int len = min(lens ? lens[b] : N, N);
-  if (blockIdx.x * (NW * 32) >= len) {  // a tile of padded queries only: their rows are zero (ragged batches)
+  if (qblk * (NW * 32) >= len) {  // a tile of padded queries only: their rows are zero (padded grids)
     for (int i = tid; i < NW * 32 * (DK / 4); i += NW * 64) {
-      const int q = blockIdx.x * (NW * 32) + i / (DK / 4);
+      const int q = qblk * (NW * 32) + i / (DK / 4);
       if (q < N) *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + (i % (DK / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
@@ -696,7 +715,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(const float* _
 // arithmetic) on attention_x3_kernel's operands.  Same bits as attention_x3_kernel.
 template <int DK, int QT>
 __global__ __launch_bounds__(QT * 128, 2) void attention_x3_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                    const int32_t* __restrict__ lens, int N, int H, float temperature) {
+                                                                    const int32_t* __restrict__ lens, int N, int H, float temperature, const RowMap rm) {
   constexpr int KS = DK + 4;
   constexpr int VS = 36;
   constexpr int DH = DK / 2, DTH = DH / 32, NSH = DH / 16;
@@ -711,12 +730,12 @@ __global__ __launch_bounds__(QT * 128, 2) void attention_x3_split_kernel(const f
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int qt = wave >> 1, part = wave & 1;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * (QT * 32) + qt * 32;
+  ATT_BLOCK_OF_GRID(QT * 32)
+  const int q0 = qblk * (QT * 32) + qt * 32;
   const int len = min(lens ? lens[b] : N, N);
-  if (blockIdx.x * (QT * 32) >= len) {
+  if (qblk * (QT * 32) >= len) {
     for (int i = tid; i < QT * 32 * (DK / 4); i += NTH) {
-      const int q = blockIdx.x * (QT * 32) + i / (DK / 4);
+      const int q = qblk * (QT * 32) + i / (DK / 4);
       if (q < N) *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + (i % (DK / 4)) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
@@ -900,7 +919,7 @@ const char* launch_rel_attention(const float* qkv, const float* ps, int ldp, con
 }
 
 const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head, int x3,
-                             hipStream_t s) {
+                             hipStream_t s, const int32_t* lens_host) {
   if (!qkv || !out) return "attention: null pointer";
   if (B <= 0 || N <= 0 || n_head <= 0 || H % n_head) return "attention: bad dims";
   if (((uintptr_t)qkv | (uintptr_t)out) & 15) return "attention: buffers must be 16-byte aligned";
@@ -915,12 +934,23 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
   static const long long split_env = getenv("E2ETTS_ATT_SPLIT_MAX") ? atoll(getenv("E2ETTS_ATT_SPLIT_MAX")) : -1;
   const long long split_max = split_env >= 0 ? split_env : (x3 ? 512 : (1LL << 62));
   dim3 gs((N + 63) / 64, n_head, B);
+  // ragged batch, lengths known on the host: the compact 1-D grid of the query blocks that exist (kernels.h: RowMap)
+  RowMap rm;
+  auto shape = [&](dim3 padded, int qrows) -> dim3 {
+    rm.n = 0;
+    if (!lens || !lens_host || B > ROWMAP_MAX) return padded;
+    rm.n = B;
+    rm.cum[0] = 0;
+    for (int b = 0; b < B; ++b) rm.cum[b + 1] = rm.cum[b] + (std::min(std::max(lens_host[b], 0), N) + qrows - 1) / qrows * n_head;
+    return dim3((unsigned)std::max(rm.cum[B], 1));
+  };
   const bool split = (dk == 64 || dk == 128 || dk == 192) && (long long)gs.x * gs.y * gs.z <= split_max;
   if (x3 && split) {
+    const dim3 gc = shape(gs, 64);
     switch (dk) {
-      case 64: hipLaunchKernelGGL((attention_x3_split_kernel<64, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 128: hipLaunchKernelGGL((attention_x3_split_kernel<128, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      default: hipLaunchKernelGGL((attention_x3_split_kernel<192, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 64: hipLaunchKernelGGL((attention_x3_split_kernel<64, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+      case 128: hipLaunchKernelGGL((attention_x3_split_kernel<128, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+      default: hipLaunchKernelGGL((attention_x3_split_kernel<192, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
     }
     return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
   }
@@ -928,40 +958,44 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
     static const int nw = getenv("E2ETTS_ATT_NW") ? atoi(getenv("E2ETTS_ATT_NW")) : 8;  // tuning aid
     if (nw == 8) {
       dim3 g8((N + 255) / 256, n_head, B);
+      const dim3 gc = shape(g8, 256);
       switch (dk) {
-        case 32: hipLaunchKernelGGL((attention_x3_kernel<32, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
-        case 64: hipLaunchKernelGGL((attention_x3_kernel<64, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
-        case 96: hipLaunchKernelGGL((attention_x3_kernel<96, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
-        case 128: hipLaunchKernelGGL((attention_x3_kernel<128, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
-        case 192: hipLaunchKernelGGL((attention_x3_kernel<192, 8>), g8, dim3(512), 0, s, qkv, out, lens, N, H, temperature); break;
+        case 32: hipLaunchKernelGGL((attention_x3_kernel<32, 8>), gc, dim3(512), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+        case 64: hipLaunchKernelGGL((attention_x3_kernel<64, 8>), gc, dim3(512), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+        case 96: hipLaunchKernelGGL((attention_x3_kernel<96, 8>), gc, dim3(512), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+        case 128: hipLaunchKernelGGL((attention_x3_kernel<128, 8>), gc, dim3(512), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+        case 192: hipLaunchKernelGGL((attention_x3_kernel<192, 8>), gc, dim3(512), 0, s, qkv, out, lens, N, H, temperature, rm); break;
         default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
       }
       return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
     }
+    const dim3 gc = shape(grid, 128);
     switch (dk) {
-      case 32: hipLaunchKernelGGL((attention_x3_kernel<32, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 64: hipLaunchKernelGGL((attention_x3_kernel<64, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 96: hipLaunchKernelGGL((attention_x3_kernel<96, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 128: hipLaunchKernelGGL((attention_x3_kernel<128, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 192: hipLaunchKernelGGL((attention_x3_kernel<192, 4>), grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 32: hipLaunchKernelGGL((attention_x3_kernel<32, 4>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+      case 64: hipLaunchKernelGGL((attention_x3_kernel<64, 4>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+      case 96: hipLaunchKernelGGL((attention_x3_kernel<96, 4>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+      case 128: hipLaunchKernelGGL((attention_x3_kernel<128, 4>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+      case 192: hipLaunchKernelGGL((attention_x3_kernel<192, 4>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
       default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
     }
     return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
   }
   if (split) {
+    const dim3 gc = shape(gs, 64);
     switch (dk) {
-      case 64: hipLaunchKernelGGL((attention_split_kernel<64, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      case 128: hipLaunchKernelGGL((attention_split_kernel<128, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-      default: hipLaunchKernelGGL((attention_split_kernel<192, 2>), gs, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+      case 64: hipLaunchKernelGGL((attention_split_kernel<64, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+      case 128: hipLaunchKernelGGL((attention_split_kernel<128, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+      default: hipLaunchKernelGGL((attention_split_kernel<192, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
     }
     return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
   }
+  const dim3 gc = shape(grid, 128);
   switch (dk) {
-    case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-    case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-    case 96: hipLaunchKernelGGL(attention_kernel<96>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-    case 128: hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
-    case 192: hipLaunchKernelGGL(attention_kernel<192>, grid, dim3(256), 0, s, qkv, out, lens, N, H, temperature); break;
+    case 32: hipLaunchKernelGGL(attention_kernel<32>, gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+    case 64: hipLaunchKernelGGL(attention_kernel<64>, gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+    case 96: hipLaunchKernelGGL(attention_kernel<96>, gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+    case 128: hipLaunchKernelGGL(attention_kernel<128>, gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+    case 192: hipLaunchKernelGGL(attention_kernel<192>, gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
     default: return "attention: head dim must be one of 32, 64, 96, 128, 192";
   }
   return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";

@@ -27,6 +27,7 @@
 // tile, in every arithmetic mode since round 2 -- as MFMA fragments straight from L2, in an order written once at load time
 // (launch_x3_to_frag / launch_f32_to_frag): no LDS weight tile, no barrier per tap.  The grid is one-dimensional and XCD-aware: the
 // column tiles of a row group run next to each other on one XCD's L2 (see the kernel's prologue).
+#include <algorithm>
 #include <cstdlib>
 
 #include "host_logic.h"
@@ -114,7 +115,7 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
 // short, irregular iterations) LOSE 8-15 % at three waves, so launch_cfg keeps them -- and every other tile shape -- at OCC = 2.
 template <int BM, int BN, int WM, int WN, int MODE, bool ACCUM, bool VEC, bool BFRAG, int CPI = 0, int OCC = 2>
 __global__ __launch_bounds__(256, OCC) void conv_gemm_kernel(const ConvParams p, const int tiles_per_block,
-                                                                                                      const int gx, const int ny) {
+                                                                                                      const int gx, const int ny, const RowMap rm) {
   constexpr bool K1 = CPI > 0;
   static_assert(!K1 || BFRAG, "multi-chunk items exist on the fragment path only");
   constexpr bool X3 = MODE != 0;
@@ -154,8 +155,14 @@ __global__ __launch_bounds__(256, OCC) void conv_gemm_kernel(const ConvParams p,
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int by = slot % ny;
   const int g = (slot / ny) * 8 + xcd;
-  if (g >= gx * p.B) return;  // the padding of the grid to a multiple of 8 row groups
-  const int b = g / gx, bx = g - b * gx;
+  int b, bx;
+  if (rm.n > 0) {  // ragged batch, compact grid: every row group of the grid has rows to compute (kernels.h: RowMap)
+    if (!rowmap_find(rm, g, b, bx)) return;  // the padding of the grid to a multiple of 8 row groups
+  } else {
+    if (g >= gx * p.B) return;
+    b = g / gx;
+    bx = g - b * gx;
+  }
   const int n0 = by * BN;
   // ragged batches: rows >= act_rows[b] are not needed by anyone (see engine.hip) -- whole tiles beyond them are skipped
   const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
@@ -628,16 +635,33 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   // last round of workgroups ran a third empty: 110-118 instead of 137-140 TFLOP/s on the mixed-length batch.  24 rather than the
   // earlier 8 for the same reason: a mixed-length batch ends every utterance in a partial group, and with 2-3 workgroups resident per
   // CU eight groups per CU are only three or four rounds -- 140.5 -> 135.4 ms/step on BASELINE config 3, the fixed-length batch unchanged)
-  const long long total = (long long)((double)mtiles * ntiles * p.B * (p.act_frac > 0.0 && p.act_frac <= 1.0 ? p.act_frac : 1.0));
+  const bool compact = p.act_rows && p.act_rows_host && p.B <= ROWMAP_MAX;  // ragged, lengths known on the host: no empty workgroups
+  long long real_tiles = 0;  // row tiles that have rows to compute
+  if (compact)
+    for (int b = 0; b < p.B; ++b) real_tiles += (std::min(std::max(p.act_rows_host[b], 0), p.T) + BM - 1) / BM;
+  const long long total = compact ? real_tiles * ntiles
+                                  : (long long)((double)mtiles * ntiles * p.B * (p.act_frac > 0.0 && p.act_frac <= 1.0 ? p.act_frac : 1.0));
   static const int wg_per_cu = getenv("E2ETTS_WG_PER_CU") ? atoi(getenv("E2ETTS_WG_PER_CU")) : 24;  // tuning aid
   int tpb = (int)(total / (256 * wg_per_cu));
   tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
   if (tpb > mtiles) tpb = mtiles;
-  const int gx = (mtiles + tpb - 1) / tpb;                        // row groups per utterance
-  const long long groups8 = ((long long)gx * p.B + 7) / 8;        // row groups per XCD
+  const int gx = (mtiles + tpb - 1) / tpb;                        // row groups per utterance (padded length)
+  RowMap rm;
+  long long groups = (long long)gx * p.B;
+  if (compact) {  // row groups per utterance from ITS rows; the kernel re-derives the same counts from act_rows[b] on the device
+    rm.n = p.B;
+    rm.cum[0] = 0;
+    for (int b = 0; b < p.B; ++b) {
+      const int mt = (std::min(std::max(p.act_rows_host[b], 0), p.T) + BM - 1) / BM;
+      rm.cum[b + 1] = rm.cum[b] + (mt + tpb - 1) / tpb;
+    }
+    groups = rm.cum[p.B];
+    if (groups == 0) return nullptr;  // no utterance has a row to compute
+  }
+  const long long groups8 = (groups + 7) / 8;                     // row groups per XCD
   if (groups8 * 8 * ntiles >= (1LL << 31)) return "conv_gemm: grid too large";
   dim3 grid((unsigned)(groups8 * 8 * ntiles));
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI, OCC>), grid, dim3(256), lds, s, p, tpb, gx, ntiles);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, MODE, ACCUM, VEC, BFRAG, CPI, OCC>), grid, dim3(256), lds, s, p, tpb, gx, ntiles, rm);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_gemm: launch failed";
 }
 
@@ -682,18 +706,33 @@ const char* launch_cfg(const ConvParams& p, hipStream_t s) {
 // the workgroups at half the work, e.g. 3 half-rounds instead of 2 full ones.  Same per-wave MFMA : fragment ratio (MT = 2).
 // (under one round of 128 x 128 tiles but many rows -- host_logic.h -- the fragment path takes 64 x 128, accumulate or not; without
 // fragment-order weights such a launch stays on 64 x 64)
+// (the counts are those of the tiles that really run: a ragged batch whose lengths the host knows is sized on them, host_logic.h)
+static void launch_counts(const ConvParams& p, long long* t128, long long* rows) {
+  if (p.act_rows && p.act_rows_host) {
+    ragged_counts(p.act_rows_host, p.B, p.T, p.Cout, t128, rows);
+  } else {
+    *t128 = tiles_128(p.B, p.T, p.Cout);
+    *rows = (long long)p.B * p.T;
+  }
+}
 static bool under_round_many_rows(const ConvParams& p) {
-  return p.Cout > 64 && tiles_128(p.B, p.T, p.Cout) < 2 * 256 && tile_many_rows(p.B, p.T);
+  long long t128, rows;
+  launch_counts(p, &t128, &rows);
+  return p.Cout > 64 && t128 < 2 * 256 && tile_many_rows_n(rows);
 }
 bool few_rows(const ConvParams& p) {  // host_logic.h
-  return tile_few_rows(p.B, p.T, p.Cout) || (!p.wfrag && under_round_many_rows(p));
+  long long t128, rows;
+  launch_counts(p, &t128, &rows);
+  return tile_few_rows_n(t128, rows, p.Cout) || (!p.wfrag && under_round_many_rows(p));
 }
 bool half_rows(const ConvParams& p) {
   static const bool on = !(getenv("E2ETTS_HALF_ROWS") && atoi(getenv("E2ETTS_HALF_ROWS")) == 0);  // tuning aid
   if (!p.wfrag) return false;
   if (under_round_many_rows(p)) return true;
   if (!on || p.accumulate) return false;
-  return tile_half_rows(p.B, p.T, p.Cout);
+  long long t128, rows;
+  launch_counts(p, &t128, &rows);
+  return tile_half_rows_n(t128, rows, p.Cout);
 }
 
 bool epilogue_vec_ok(const ConvParams& p) {

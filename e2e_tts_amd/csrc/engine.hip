@@ -134,6 +134,8 @@ struct e2etts_engine {
   bool st_open = false, st_done = false;
   int ragged = 1;         // synthesize(): skip rows of shorter utterances that no valid output sample depends on
   DevBuf actbuf;          // [2 + voc_stages + 1][B] int32 row limits
+  std::vector<int32_t> h_act;  // the same limits on the host, same layout (valid for the call that computed them): the launchers build
+                               // their compact grids from them (kernels.h: RowMap)
   double rag_frac_dec = 1.0, rag_frac_post = 1.0, rag_frac_voc = 1.0;  // fraction of the padded rows those limits leave (profile FLOP counts)
   int dec_precision = 0;  // same choice for decoder + mel_linear + postnet (encoder / variance adaptor: always fp32)
 
@@ -616,7 +618,7 @@ int bind_vocoder(e2etts_engine* e) {
 
 // 6 x FFTBlock (reference U/blocks/transformer.py:178-189), in place on x ([B, N, H]); lens32: device [B]
 int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3,
-              const int32_t* act = nullptr, double act_frac = 1.0, bool ksplit = false) {
+              const int32_t* act = nullptr, double act_frac = 1.0, bool ksplit = false, const int32_t* act_host = nullptr) {
   const auto& c = e->cfg;
   const int H = c.hidden, F = c.ffn_dim;
   float* qkv = ptr<float>(e->qkv);
@@ -625,7 +627,7 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
   float* hid = ptr<float>(e->hid);
   for (const FFTLayer& f : layers) {
     ConvParams p;
-    p.B = B; p.T = N; p.act_rows = act; p.act_frac = act_frac;
+    p.B = B; p.T = N; p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;
     // q | k | v projections as one GEMM (U/blocks/transformer.py:220-222)
     const bool sx = x3 && f.wqkv_x3;
     p.in = x; p.w = sx ? f.wqkv_x3 : f.wqkv; p.x3 = sx; p.bias = f.bqkv; p.out = qkv; p.Cin = H; p.Cout = 3 * H;
@@ -636,7 +638,7 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
       KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, sx ? 1 : 0, e->stream));
     }
     // fc + residual (:238-239), LayerNorm eps 1e-5, masked_fill (:182-183)
-    p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_frac = act_frac;
+    p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;
     p.in = att; p.w = sx ? f.wo_x3 : f.wo; p.x3 = sx; p.bias = f.bo; p.res = x; p.out = tmp; p.Cin = H; p.Cout = H;
     RET(conv(e, p, 1.0, ksplit));
     {
@@ -644,11 +646,11 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
       KCHK(e, launch_layernorm(tmp, xalt, f.ln1g, f.ln1b, lens, B, N, H, 1e-5f, e->stream));
     }
     // conv k9 + ReLU, conv k1 + residual, LayerNorm, masked_fill (:289-297, :185-187)
-    p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_frac = act_frac;
+    p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;
     p.in = xalt; p.w = sx ? f.w1_x3 : f.w1; p.x3 = sx; p.bias = f.b1; p.out = hid; p.Cin = H; p.Cout = F; p.KW = c.ffn_k1; p.pad = (c.ffn_k1 - 1) / 2;
     p.act = ACT_RELU;
     RET(conv(e, p, 1.0, ksplit));
-    p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_frac = act_frac;
+    p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;
     p.in = hid; p.w = sx ? f.w2_x3 : f.w2; p.x3 = sx; p.bias = f.b2; p.res = xalt; p.out = tmp; p.Cin = F; p.Cout = H;
     RET(conv(e, p, 1.0, ksplit));
     {
@@ -928,7 +930,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   // kernels write zeros there), so its convolutions compute rows < mel_len only and valid rows stay bit-identical.
   // mel_linear / postnet are unmasked and the vocoder reads `halo` frames past the end, so they compute rows
   // < mel_len + halo + 2 * postnet_layers; rows beyond hold stale finite values that no valid sample depends on.
-  const int32_t *act_dec = nullptr, *act_post = nullptr;
+  const int32_t *act_dec = nullptr, *act_post = nullptr, *act_dec_h = nullptr, *act_post_h = nullptr;
   if (ragged) {
     RET(ensure(e, e->actbuf, (size_t)(3 + c.voc_stages) * B * 4));
     int32_t* ab = ptr<int32_t>(e->actbuf);
@@ -939,18 +941,24 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     act_post = ab + B;
     double sd = 0, sp = 0, sv = 0;  // the same limits on the host (mel lengths are in e->h_mel since the sync above)
     const long long add_post = halo + 2 * c.postnet_layers * ((c.postnet_kernel - 1) / 2);
+    e->h_act.assign((size_t)(3 + c.voc_stages) * B, 0);
     for (int b = 0; b < B; ++b) {
+      const long long m32 = std::min<long long>(e->h_mel[b], 0x7fffffffLL);  // what duration_kernel wrote to mel32 (act_rows_kernel's input)
+      e->h_act[b] = (int32_t)std::min<long long>(m32, T);
+      e->h_act[(size_t)B + b] = (int32_t)std::min<long long>(m32 + add_post, T);
       sd += (double)std::min<long long>(e->h_mel[b], T);
       sp += (double)std::min<long long>(e->h_mel[b] + add_post, T);
       sv += (double)std::min<long long>(e->h_mel[b] + halo, T);
     }
+    act_dec_h = e->h_act.data();
+    act_post_h = e->h_act.data() + B;
     e->rag_frac_dec = sd / ((double)B * T);
     e->rag_frac_post = sp / ((double)B * T);
     e->rag_frac_voc = sv / ((double)B * T);
   }
   // (a Conformer decoder computes every row: its attention is unmasked and its depthwise convolution crosses into the padding)
   if (c.block_type == 1) RET(conformer_stack(e, e->cf_dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1));
-  else RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1, act_dec, act_dec ? e->rag_frac_dec : 1.0));
+  else RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1, act_dec, act_dec ? e->rag_frac_dec : 1.0, false, act_dec_h));
   // mel_linear (U/model.py:186)
   ConvParams p;
   auto setw = [&](ConvParams& q, const ConvW& w) {
@@ -958,7 +966,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     if (e->dec_precision == 1 && w.wx3) { q.w = w.wx3; q.x3 = 1; }
     else { q.w = w.w; q.x3 = 0; }
   };
-  p.B = B; p.T = (int)T; p.act_rows = act_post; p.act_frac = act_post ? e->rag_frac_post : 1.0; p.in = dx; setw(p, e->mel_lin); p.out = ptr<float>(e->mel); p.Cin = H; p.Cout = c.n_mel;
+  p.B = B; p.T = (int)T; p.act_rows = act_post; p.act_rows_host = act_post_h; p.act_frac = act_post ? e->rag_frac_post : 1.0; p.in = dx; setw(p, e->mel_lin); p.out = ptr<float>(e->mel); p.Cin = H; p.Cout = c.n_mel;
   RET(conv(e, p));
   // Postnet (U/layers.py:556-563; BatchNorm folded at pack time) + residual (U/model.py:188); unmasked
   const float* pin = ptr<float>(e->mel);
@@ -967,7 +975,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   for (int i = 0; i < c.postnet_layers; ++i) {
     const bool last = i == c.postnet_layers - 1;
     p = ConvParams();
-    p.B = B; p.T = (int)T; p.act_rows = act_post; p.act_frac = act_post ? e->rag_frac_post : 1.0; p.in = pin; setw(p, e->postnet[i]); p.Cin = cin;
+    p.B = B; p.T = (int)T; p.act_rows = act_post; p.act_rows_host = act_post_h; p.act_frac = act_post ? e->rag_frac_post : 1.0; p.in = pin; setw(p, e->postnet[i]); p.Cin = cin;
     p.Cout = last ? c.n_mel : c.postnet_dim; p.KW = c.postnet_kernel; p.pad = (c.postnet_kernel - 1) / 2;
     if (last) { p.out = ptr<float>(e->melpost); p.res = ptr<float>(e->mel); }
     else { p.out = bufs[i & 1]; p.act = ACT_TANH; }
@@ -981,7 +989,8 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
 }
 
 // HifiGan.forward (V/generator.py:37-53) on channels-last mel [B, T, n_mel] already in HBM
-int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want_wav, bool want_pcm, const int32_t* ragged_lens = nullptr) {
+int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want_wav, bool want_pcm, const int32_t* ragged_lens = nullptr,
+                 const int64_t* ragged_lens_host = nullptr) {
   const auto& c = e->cfg;
   if (!e->voc_loaded) return e->fail(E2ETTS_ESTATE, "vocoder weights not loaded");
   if (B <= 0 || T <= 0) return e->fail(E2ETTS_EINVAL, "B and T must be positive");
@@ -1017,14 +1026,24 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   // Ragged mode: utterance b needs output frames < mel_len + halo only (halo = receptive field of the whole generator in
   // frames); each stage computes those frames at its own rate.  What lies beyond is stale but finite and out of reach.
   const int32_t* act_stage[E2ETTS_MAX_STAGES + 1] = {nullptr};
+  const int32_t* act_stage_h[E2ETTS_MAX_STAGES + 1] = {nullptr};  // the same limits in host memory (compact grids), when the caller has the lengths there
   if (ragged_lens) {
     RET(ensure(e, e->actbuf, (size_t)(3 + c.voc_stages) * B * 4));
     int32_t* ab = ptr<int32_t>(e->actbuf) + 2 * B;
     const int halo = vocoder_halo_frames(c);
+    if (ragged_lens_host) e->h_act.resize((size_t)(3 + c.voc_stages) * B, 0);
     long long rate = 1;
     for (int i = 0; i <= c.voc_stages; ++i) {
       KCHK(e, launch_act_rows(ragged_lens, ab + (size_t)i * B, B, halo, (int)rate, (long long)T * rate, e->stream));
       act_stage[i] = ab + (size_t)i * B;
+      if (ragged_lens_host) {  // act_rows_kernel's arithmetic on the host copy of its input
+        int32_t* h = e->h_act.data() + (size_t)(2 + i) * B;
+        for (int b = 0; b < B; ++b) {
+          const long long m32 = std::min<long long>(ragged_lens_host[b], 0x7fffffffLL);
+          h[b] = (int32_t)std::min<long long>((m32 + halo) * rate, (long long)T * rate);
+        }
+        act_stage_h[i] = h;
+      }
       if (i < c.voc_stages) rate *= c.voc_up_rate[i];
     }
   }
@@ -1064,7 +1083,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     }
   } drain{e, conc ? nk - 1 : 0, false};
   ConvParams p;
-  p.B = B; p.T = T; p.act_rows = act_stage[0]; p.act_frac = vf; p.in = mel_btc; setw(p, e->voc_pre); p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
+  p.B = B; p.T = T; p.act_rows = act_stage[0]; p.act_rows_host = act_stage_h[0]; p.act_frac = vf; p.in = mel_btc; setw(p, e->voc_pre); p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
   p.KW = 7; p.pad = 3;
   RET(conv(e, p));
   long long n = T;
@@ -1075,7 +1094,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     // leaky_relu(0.1) -> ConvTranspose1d(k = 2s, stride s, pad s/2)  (V/generator.py:40-41) as a 3-tap convolution
     // with s * co output channels: row q of the [n, s*co] result IS rows q*s .. q*s+s-1 of the [n*s, co] signal.
     p = ConvParams();
-    p.B = B; p.T = (int)n; p.act_rows = act_stage[i]; p.act_frac = vf; p.in = S; setw(p, e->voc_up[i]); p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
+    p.B = B; p.T = (int)n; p.act_rows = act_stage[i]; p.act_rows_host = act_stage_h[i]; p.act_frac = vf; p.in = S; setw(p, e->voc_up[i]); p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
     p.KW = 3; p.pad = 1; p.in_slope = 0.1f;
     p.zero_tap_split = s * co / 2;  // phases < s/2 never use tap 2, the others never tap 0 (packer.polyphase_upsampler)
     RET(conv(e, p, 2.0 / 3.0));
@@ -1116,7 +1135,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         ChainParams q;
         q.x = XU; q.wfrag = e->rb_pair_frag[idx][0]; q.out = S;
         for (int m = 0; m < 3; ++m) { q.b1[m] = e->rb_c1[idx][m].b; q.b2[m] = e->rb_c2[idx][m].b; q.dil[m] = c.voc_rb_dil[j][m]; }
-        q.act_rows = act_stage[i + 1]; q.act_frac = vf;
+        q.act_rows = act_stage[i + 1]; q.act_rows_host = act_stage_h[i + 1]; q.act_frac = vf;
         q.B = B; q.T = (int)n; q.C = co; q.KW = k;
         q.x_bs = q.out_bs = (long long)n * co;
         q.slope = 0.1f; q.mode = e->voc_precision;
@@ -1133,7 +1152,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         PairParams q;
         q.x = cur; q.wfrag = f32 ? e->rb_pair_frag32[idx][m] : e->rb_pair_frag[idx][m]; q.b1 = e->rb_c1[idx][m].b; q.b2 = e->rb_c2[idx][m].b;
         q.out = last ? S : (cur == CUR ? T1 : CUR);
-        q.act_rows = act_stage[i + 1]; q.act_frac = vf;
+        q.act_rows = act_stage[i + 1]; q.act_rows_host = act_stage_h[i + 1]; q.act_frac = vf;
         q.B = B; q.T = (int)n; q.C = co; q.KW = k; q.dil = c.voc_rb_dil[j][m];
         q.x_bs = q.out_bs = (long long)n * co;
         q.slope = 0.1f; q.mode = e->voc_precision;
@@ -1155,7 +1174,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         // ResBlock2 (V/layers.py:59-63): x = c(lrelu(x)) + x per dilation; the last one adds into the stage sum
         const bool last = m == c.voc_n_dil - 1;
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_frac = vf; p.in = cur; setw(p, e->rb_c1[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vf; p.in = cur; setw(p, e->rb_c1[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = c.voc_rb_dil[j][m]; p.pad = (k * p.dil - p.dil) / 2; p.in_slope = 0.1f;
         if (last) {
           p.out = S;
@@ -1171,14 +1190,14 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         const int d = c.voc_rb_dil[j][m];
         // xt = c1(lrelu(x)); the lrelu that feeds c2 is applied here, in c1's epilogue (V/layers.py:35-38)
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_frac = vf; p.in = cur; setw(p, e->rb_c1[idx][m]); p.out = T1; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vf; p.in = cur; setw(p, e->rb_c1[idx][m]); p.out = T1; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = d; p.pad = (k * d - d) / 2; p.in_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f;
         RET(conv(e, p));
         // x = c2(xt) + x (:38-39); the last pair adds into the stage sum, and the last ResBlock divides by num_kernels
         // (V/generator.py:44-48)
         const bool last = m == c.voc_n_dil - 1;
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_frac = vf; p.in = T1; setw(p, e->rb_c2[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vf; p.in = T1; setw(p, e->rb_c2[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = 1; p.pad = (k - 1) / 2;
         if (last) {
           p.out = S;
@@ -1507,7 +1526,7 @@ int e2etts_synthesize(e2etts_engine* e, const int64_t* ids, const int64_t* lens,
   const bool ragged = e->ragged != 0;
   RET(acoustic_impl(e, ids, lens, B, L, speaker, n_spk_ids, d_control, p_control, e_control, ragged));
   if (T_out) *T_out = e->last_T;
-  RET(vocoder_impl(e, ptr<float>(e->melpost), B, e->last_T, false, true, ragged ? ptr<int32_t>(e->mel32) : nullptr));
+  RET(vocoder_impl(e, ptr<float>(e->melpost), B, e->last_T, false, true, ragged ? ptr<int32_t>(e->mel32) : nullptr, ragged ? e->h_mel : nullptr));
   if (mel_lens_out) RET(copy_out(e, mel_lens_out, e->mel64.p, (size_t)B * 8));
   const size_t ns = (size_t)B * e->last_T * e->cfg.hop_length;
   if (pcm_out) {

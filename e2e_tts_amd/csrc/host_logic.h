@@ -139,14 +139,31 @@ inline long long tiles_128(int B, int T, int Cout) {  // 128 x 128 tiles of the 
 // 384 workgroups whose waves each fetch their own weight fragments for ONE 32 x 32 MFMA tile -- that launch waits on L2 bandwidth
 // (540 MB of fragments in 55 us) -- so those run as 64 x 128 too: 192 workgroups, two MFMA row tiles per fragment (B = 1 step: 9.46 ->
 // 9.05 ms fp32, 5.21 -> 5.11 ms bf16x3; B = 4: -4 %).  With fewer rows (the decoder at B <= 4, the encoder) 64 x 64 stayed ahead.
-inline bool tile_many_rows(int B, int T) { return (long long)B * T >= 6144; }
-inline bool tile_few_rows(int B, int T, int Cout) { return Cout > 64 && tiles_128(B, T, Cout) < 2 * 256 && !tile_many_rows(B, T); }
-inline bool tile_half_rows(int B, int T, int Cout) {
-  if (Cout <= 64 || tile_few_rows(B, T, Cout)) return false;
-  if (tiles_128(B, T, Cout) < 2 * 256) return true;  // under one round, many rows
-  const long long wg = tiles_128(B, T, Cout), slots = 2 * 256;
-  const long long r128 = (wg + slots - 1) / slots, r64 = (2 * wg + slots - 1) / slots;
+// The predicates on counts (t128 = 128 x 128 tiles of the launch, rows = output rows of the launch): a ragged batch passes the tiles and
+// rows that really run (conv_gemm.hip counts them from ConvParams::act_rows_host), a padded one those of B x T.
+inline bool tile_many_rows_n(long long rows) { return rows >= 6144; }
+inline bool tile_few_rows_n(long long t128, long long rows, int Cout) { return Cout > 64 && t128 < 2 * 256 && !tile_many_rows_n(rows); }
+inline bool tile_half_rows_n(long long t128, long long rows, int Cout) {
+  if (Cout <= 64 || tile_few_rows_n(t128, rows, Cout)) return false;
+  if (t128 < 2 * 256) return true;  // under one round, many rows
+  const long long slots = 2 * 256;
+  const long long r128 = (t128 + slots - 1) / slots, r64 = (2 * t128 + slots - 1) / slots;
   return 0.5 * 1.06 * (double)r64 < (double)r128;
+}
+inline bool tile_many_rows(int B, int T) { return tile_many_rows_n((long long)B * T); }
+inline bool tile_few_rows(int B, int T, int Cout) { return tile_few_rows_n(tiles_128(B, T, Cout), (long long)B * T, Cout); }
+inline bool tile_half_rows(int B, int T, int Cout) { return tile_half_rows_n(tiles_128(B, T, Cout), (long long)B * T, Cout); }
+
+// 128 x 128 tiles and rows of a ragged launch: utterance b computes min(rows[b], T) rows (rows = ConvParams::act_rows_host)
+inline void ragged_counts(const int32_t* rows, int B, int T, int Cout, long long* t128, long long* nrows) {
+  long long t = 0, r = 0;
+  for (int b = 0; b < B; ++b) {
+    const long long v = rows[b] < 0 ? 0 : (rows[b] > T ? T : rows[b]);
+    t += (v + 127) / 128;
+    r += v;
+  }
+  *t128 = t * (((long long)Cout + 127) / 128);
+  *nrows = r;
 }
 
 }  // namespace e2etts

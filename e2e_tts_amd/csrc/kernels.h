@@ -9,6 +9,27 @@ namespace e2etts {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_SWISH = 4 /* v * sigmoid(v), Conformer FFN */ };
 
+// Compact grid of a RAGGED batch.  A launch whose utterances need different numbers of rows must not contain workgroups that find nothing
+// to do: the hardware places workgroups on CUs in a fixed rotation, not by load, so runs of workgroups that exit at once leave some
+// CUs with a multiple of the others' work (tools/dispatch_rate.hip: 3072 busy workgroups with 60 % more empties among them take 1.25 x
+// to 1.75 x as long as without them; a mixed-length batch lost 10 % on the 256-channel vocoder stage this way).  The launcher therefore
+// counts each utterance's units (row groups, tiles, query tiles ...) on the HOST -- the engine holds the mel lengths there after its one
+// synchronisation -- and the kernel finds its utterance by a scan over this table, which travels in the kernel arguments.
+constexpr int ROWMAP_MAX = 64;  // utterances per launch the table holds; larger ragged batches keep the padded grid
+struct RowMap {
+  int n = 0;                  // 0: uniform grid (every utterance has the same number of units)
+  int cum[ROWMAP_MAX + 1];    // cum[b] = units of utterances < b; cum[n] = all units
+};
+// (b, local unit) of unit g; false when g lies beyond the last unit (the grid is padded to a multiple of 8)
+__device__ __forceinline__ bool rowmap_find(const RowMap& rm, int g, int& b, int& local) {
+  if (g >= rm.cum[rm.n]) return false;
+  int k = 0;
+  for (int i = 1; i < rm.n; ++i) k += g >= rm.cum[i] ? 1 : 0;
+  b = k;
+  local = g - rm.cum[k];
+  return true;
+}
+
 // out[b, t, n] = epilogue( sum_{j < KW} sum_{c < Cin} f(in[b, t - pad + j*dil, c]) * w[n, j*Cin + c] )
 // "same" 1-D convolution as an implicit GEMM on the fp32 MFMA (M = time, N = Cout, K = KW*Cin);
 // KW == 1 is a plain Linear.  Rows outside [0, T) read as zero (zero padding).
@@ -26,6 +47,8 @@ struct ConvParams {
   float* out = nullptr;          // [B, T, Cout]
   const int32_t* lens = nullptr; // optional [B]: output rows t >= lens[b] are written as 0
   const int32_t* act_rows = nullptr; // optional [B]: only output rows < act_rows[b] are computed at all (ragged batches)
+  const int32_t* act_rows_host = nullptr;  // the same B values in HOST memory (launcher only): with them the grid holds no workgroup
+                                     // without rows (RowMap above) and the tile shape is chosen on the tiles that really run
   int B = 0, T = 0, Cin = 0, Cout = 0, KW = 1, dil = 1, pad = 0;
   long long in_bs = 0, out_bs = 0, res_bs = 0;
   int in_ld = 0, out_ld = 0, res_ld = 0;
@@ -56,8 +79,10 @@ const char* launch_conv_rows(const ConvParams& p, hipStream_t s);
 // Fused masked self-attention on the packed QKV buffer of one FFT block.
 // qkv [B, N, 3H] (q | k | v, head h at columns h*dk .. (h+1)*dk of each third); keys >= lens[b] masked (-inf);
 // out [B, N, H]; query rows >= lens[b] are written as 0 (they are zeroed after the LayerNorm anyway).
+// lens_host: the same B lengths in host memory (optional): the grid then holds only the query blocks that exist (RowMap), and the output
+// rows of queries >= lens[b] beyond the last block keep their old contents instead of being zeroed.
 const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head, int x3,
-                             hipStream_t s);
+                             hipStream_t s, const int32_t* lens_host = nullptr);
 
 // y[row, :] = LayerNorm(x[row, :]) * gamma + beta; rows t >= lens[b] -> 0 when lens != null (C <= 1024, C % 4 == 0)
 const char* launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, const int32_t* lens,
@@ -103,6 +128,7 @@ struct PairParams {
   const float* b2 = nullptr;     // [C]
   float* out = nullptr;          // [B, T, C], must not alias x
   const int32_t* act_rows = nullptr;  // optional [B]: only output rows < act_rows[b] are needed (whole tiles beyond are skipped)
+  const int32_t* act_rows_host = nullptr;  // the same values in host memory (launcher only): compact grid, see RowMap
   int B = 0, T = 0, C = 0, KW = 0, dil = 1;
   long long x_bs = 0, out_bs = 0;     // batch strides in floats
   float slope = 0.1f;            // leaky-ReLU slope of both activations
@@ -125,6 +151,7 @@ struct ChainParams {
   const float* b2[3] = {nullptr, nullptr, nullptr};
   float* out = nullptr;            // [B, T, C], must not alias x
   const int32_t* act_rows = nullptr;
+  const int32_t* act_rows_host = nullptr;  // as in PairParams
   int B = 0, T = 0, C = 0, KW = 3;
   int dil[3] = {1, 3, 5};
   long long x_bs = 0, out_bs = 0;

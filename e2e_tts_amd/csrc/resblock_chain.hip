@@ -48,7 +48,7 @@ template <int R, int C, int WM, int WN>
 constexpr int chain_threads() { return 64 * (R / WM) * (C / WN); }
 
 template <int R, int C, int WM, int WN, bool SPLIT, bool ACCUM>
-__global__ __launch_bounds__((chain_threads<R, C, WM, WN>()), 2) void resblock_chain_kernel(const ChainParams p) {
+__global__ __launch_bounds__((chain_threads<R, C, WM, WN>()), 2) void resblock_chain_kernel(const ChainParams p, const RowMap rm) {
   constexpr int NCH = C / 32;
   constexpr int NWN = C / WN;
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -76,13 +76,19 @@ __global__ __launch_bounds__((chain_threads<R, C, WM, WN>()), 2) void resblock_c
   const int wm = wave / NWN, wn = wave % NWN;
   const int li = lane & 31, lh = lane >> 5;
 
-  const int b = blockIdx.y;
+  int b, xb;  // compact 1-D grid of a ragged batch, or (x, y) of the padded grid: as in resblock_pair.hip
+  if (rm.n > 0) {
+    if (!rowmap_find(rm, (int)blockIdx.x, b, xb)) return;
+  } else {
+    b = blockIdx.y;
+    xb = blockIdx.x;
+  }
   const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
   const int mtiles = (t_act + RO - 1) / RO;
   // XCD-aware tile order, as in resblock_pair.hip: every XCD walks a contiguous eighth of this utterance's tiles
   const int eighth = (mtiles + 7) >> 3;
-  const int tile = (blockIdx.x & 7) * eighth + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= eighth || tile >= mtiles) return;
+  const int tile = (xb & 7) * eighth + (xb >> 3);
+  if ((xb >> 3) >= eighth || tile >= mtiles) return;
   const int origin = tile * RO - H;     // global position of tile row 0
 
   const float* x_b = p.x + (long long)b * p.x_bs;
@@ -331,11 +337,22 @@ const char* launch_chain_cfg(const ChainParams& p, hipStream_t s) {
   }
   const int mtiles = (p.T + RO - 1) / RO;
   dim3 grid((mtiles + 7) / 8 * 8, p.B);
+  RowMap rm;
+  if (p.act_rows && p.act_rows_host && p.B <= ROWMAP_MAX) {  // ragged: only the blocks of tiles that exist (resblock_pair.hip)
+    rm.n = p.B;
+    rm.cum[0] = 0;
+    for (int b = 0; b < p.B; ++b) {
+      const int mt = (std::min(std::max(p.act_rows_host[b], 0), p.T) + RO - 1) / RO;
+      rm.cum[b + 1] = rm.cum[b] + (mt + 7) / 8 * 8;
+    }
+    if (rm.cum[p.B] == 0) return nullptr;
+    grid = dim3(rm.cum[p.B]);
+  }
   constexpr int NTHR = chain_threads<R, C, WM, WN>();
   if (p.accumulate)
-    hipLaunchKernelGGL((resblock_chain_kernel<R, C, WM, WN, SPLIT, true>), grid, dim3(NTHR), lds, s, p);
+    hipLaunchKernelGGL((resblock_chain_kernel<R, C, WM, WN, SPLIT, true>), grid, dim3(NTHR), lds, s, p, rm);
   else
-    hipLaunchKernelGGL((resblock_chain_kernel<R, C, WM, WN, SPLIT, false>), grid, dim3(NTHR), lds, s, p);
+    hipLaunchKernelGGL((resblock_chain_kernel<R, C, WM, WN, SPLIT, false>), grid, dim3(NTHR), lds, s, p, rm);
   return hipGetLastError() == hipSuccess ? nullptr : "resblock_chain: launch failed";
 }
 

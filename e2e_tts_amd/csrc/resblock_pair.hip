@@ -65,7 +65,7 @@ constexpr int pair_threads() { return 64 * (BMI / WM) * (C / WN); }
 // MODE 0: exact fp32 (v_mfma_f32_32x32x2_f32; LDS rows hold 32 fp32 channels; fp32 fragment order of launch_f32_to_frag) -- round 2;
 // MODE 1: bf16x3 split precision; MODE 2: plain bf16 (rows hold 32 bf16 hi | 32 bf16 lo; fragment order of launch_x3_to_frag).
 template <int BMI, int C, int WM, int WN, int MODE, bool ACCUM>
-__global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) void resblock_pair_kernel(const PairParams p) {
+__global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) void resblock_pair_kernel(const PairParams p, const RowMap rm) {
   constexpr bool X3 = MODE != 0;
   constexpr bool SPLIT = MODE == 1;
   constexpr int KS = X3 ? 2 : 4;               // k-steps per 32-channel chunk: 2 x 16 (bf16 MFMA) or 4 x (4 MFMAs of k = 2) (fp32)
@@ -89,7 +89,15 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
   const int li = lane & 31, lh = lane >> 5;
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
 
-  const int b = blockIdx.y;
+  // ragged batch whose lengths the host knows: a 1-D grid that holds every utterance's blocks back to back (kernels.h: RowMap; each
+  // utterance's share is a multiple of 8 blocks, so `xb & 7` below is still the XCD the block runs on); else (xb, b) = (x, y) of the grid
+  int b, xb;
+  if (rm.n > 0) {
+    if (!rowmap_find(rm, (int)blockIdx.x, b, xb)) return;
+  } else {
+    b = blockIdx.y;
+    xb = blockIdx.x;
+  }
   const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
   const int mtiles = (t_act + BMO - 1) / BMO;
   // One tile per workgroup: many short workgroups balance better than a few persistent ones (measured: 8 workgroups per CU walking 6
@@ -99,8 +107,8 @@ __global__ __launch_bounds__((pair_threads<BMI, C, WM, WN>()), C == 32 ? 3 : 2) 
   // multiple of 8 wide) works on tile (x % 8) * ceil(mtiles / 8) + x / 8: every XCD walks a contiguous eighth of the tiles THIS
   // utterance really has (ragged batches), so all XCDs get the same share of every utterance.
   const int eighth = (mtiles + 7) >> 3;
-  const int tile = (blockIdx.x & 7) * eighth + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= eighth || tile >= mtiles) return;
+  const int tile = (xb & 7) * eighth + (xb >> 3);
+  if ((xb >> 3) >= eighth || tile >= mtiles) return;
 
   const float* x_b = p.x + (long long)b * p.x_bs;
   float* out_b = p.out + (long long)b * p.out_bs;
@@ -408,11 +416,22 @@ const char* launch_pair_cfg(const PairParams& p, hipStream_t s) {
   if (lds > PAIR_MAX_LDS) return "resblock_pair: LDS region exceeds the CU's 160 KiB";
   const int mtiles = (p.T + BMO - 1) / BMO;
   dim3 grid((mtiles + 7) / 8 * 8, p.B);  // a multiple of 8 (see the XCD-aware order in the kernel); extra blocks exit
+  RowMap rm;
+  if (p.act_rows && p.act_rows_host && p.B <= ROWMAP_MAX) {  // ragged: only the blocks of tiles that exist (at most 7 spare per utterance)
+    rm.n = p.B;
+    rm.cum[0] = 0;
+    for (int b = 0; b < p.B; ++b) {
+      const int mt = (std::min(std::max(p.act_rows_host[b], 0), p.T) + BMO - 1) / BMO;
+      rm.cum[b + 1] = rm.cum[b] + (mt + 7) / 8 * 8;
+    }
+    if (rm.cum[p.B] == 0) return nullptr;
+    grid = dim3(rm.cum[p.B]);
+  }
   constexpr int NTHR = pair_threads<BMI, C, WM, WN>();
   if (p.accumulate)
-    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, MODE, true>), grid, dim3(NTHR), lds, s, p);
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, MODE, true>), grid, dim3(NTHR), lds, s, p, rm);
   else
-    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, MODE, false>), grid, dim3(NTHR), lds, s, p);
+    hipLaunchKernelGGL((resblock_pair_kernel<BMI, C, WM, WN, MODE, false>), grid, dim3(NTHR), lds, s, p, rm);
   return hipGetLastError() == hipSuccess ? nullptr : "resblock_pair: launch failed";
 }
 

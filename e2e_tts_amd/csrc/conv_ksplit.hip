@@ -16,6 +16,7 @@
 //
 // (2) launch_conv_rows: conv_gemm's OWN arithmetic, MFMA for MFMA, for launches with few rows (the decoder and postnet convolutions of
 // the B = 1 path) -- see the comment above the kernel.  Same bits as conv_gemm, so the engine picks per launch.
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -66,7 +67,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {  
 // SPLITK (conv_ksplit, fp32 only): the four wavefronts share ONE 32-row tile and take the 32-channel chunks round-robin (wave w: chunks
 // w, w + 4, ...); their partial sums meet in LDS and wave 0 adds them as ((P0 + P1) + (P2 + P3)) -- see the head of this file.
 template <int NT, int MODE, int D, bool SPLITK>
-__global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, const int rg, const int ct) {
+__global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, const int rg, const int ct, const RowMap rm) {
   static_assert(!SPLITK || MODE == 0, "the K-split form serves the exact-fp32 phoneme-level layers");
   constexpr bool X3 = MODE != 0;
   constexpr bool SPLIT = MODE == 1;
@@ -80,8 +81,14 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, cons
   const int li = lane & 31, lh = lane >> 5;
   // column tile fastest: with ct a multiple of 8 the workgroups of one XCD (id % 8) share an eighth of the weights
   const int cy = blockIdx.x % ct, g = blockIdx.x / ct;
-  const int b = g / rg;
-  const int t0 = SPLITK ? (g - b * rg) * 32 : (g - b * rg) * 128 + wave * 32;   // rg: row tiles of 32 (SPLITK) or groups of 128
+  int b, gl;  // utterance, row unit inside it: compact grid of a ragged batch (kernels.h: RowMap) or rg units per utterance
+  if (rm.n > 0) {
+    if (!rowmap_find(rm, g, b, gl)) return;
+  } else {
+    b = g / rg;
+    gl = g - b * rg;
+  }
+  const int t0 = SPLITK ? gl * 32 : gl * 128 + wave * 32;   // units: row tiles of 32 (SPLITK) or groups of 128
   const int t_act = p.act_rows ? min(p.act_rows[b], p.T) : p.T;
   if (t0 >= t_act) return;   // !SPLITK: no workgroup barrier, a wavefront without rows simply leaves; SPLITK: uniform for the workgroup
   const int n0 = cy * (32 * NT);
@@ -304,8 +311,19 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const ConvParams p, cons
 
 }  // namespace
 
+// Row units (of `rows` output rows each) of the launch: the padded count per utterance, or -- ragged batch whose lengths the host knows --
+// only the units that have rows to compute, with the table the kernel finds its utterance in (kernels.h: RowMap).
+static long long ragged_units(const ConvParams& p, int rows, int padded_per_utt, RowMap& rm) {
+  rm.n = 0;
+  if (!(p.act_rows && p.act_rows_host && p.B <= ROWMAP_MAX)) return (long long)padded_per_utt * p.B;
+  rm.n = p.B;
+  rm.cum[0] = 0;
+  for (int b = 0; b < p.B; ++b) rm.cum[b + 1] = rm.cum[b] + (std::min(std::max(p.act_rows_host[b], 0), p.T) + rows - 1) / rows;
+  return rm.cum[p.B];
+}
+
 bool conv_ksplit_supported(const ConvParams& p) {
-  return p.wfrag && p.x3 == 0 && !p.accumulate && p.in_slope == 1.0f && p.zero_tap_split == 0 && !p.act_rows && p.KW >= 1 && p.dil >= 1 &&
+  return p.wfrag && p.x3 == 0 && !p.accumulate && p.in_slope == 1.0f && p.zero_tap_split == 0 && p.KW >= 1 && p.dil >= 1 &&
          p.dil * (p.KW - 1) <= KS_MAX_HALO && p.pad >= 0 && p.pad <= p.dil * (p.KW - 1) && (p.Cin % 4) == 0 && (p.in_ld % 4) == 0;
 }
 
@@ -320,10 +338,13 @@ const char* launch_conv_ksplit(const ConvParams& p, hipStream_t s) {
   // 64-column tiles halve the slab traffic per MFMA; 32-column tiles when that would leave most CUs without a workgroup
   const bool wide = p.Cout > 32 && (long long)rt * ((p.Cout + 63) / 64) * p.B >= 256;
   const int ct = wide ? (p.Cout + 63) / 64 : (p.Cout + 31) / 32;
-  const long long nwg = (long long)ct * rt * p.B;
+  RowMap rm;
+  const long long units = ragged_units(p, 32, rt, rm);
+  if (units == 0) return nullptr;
+  const long long nwg = (long long)ct * units;
   if (nwg >= (1LL << 31)) return "conv_ksplit: grid too large";
-  if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 0, 3, true>), dim3((unsigned)nwg), dim3(256), 0, s, p, rt, ct);
-  else hipLaunchKernelGGL((conv_rows_kernel<1, 0, 3, true>), dim3((unsigned)nwg), dim3(256), 0, s, p, rt, ct);
+  if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 0, 3, true>), dim3((unsigned)nwg), dim3(256), 0, s, p, rt, ct, rm);
+  else hipLaunchKernelGGL((conv_rows_kernel<1, 0, 3, true>), dim3((unsigned)nwg), dim3(256), 0, s, p, rt, ct, rm);
   return hipGetLastError() == hipSuccess ? nullptr : "conv_ksplit: launch failed";
 }
 
@@ -344,19 +365,22 @@ const char* launch_conv_rows(const ConvParams& p, hipStream_t s) {
   // 64-column tiles halve the slab traffic and LDS reads per MFMA; 32-column tiles when that would leave CUs without a workgroup
   const bool wide = p.Cout > 32 && (long long)rg * ((p.Cout + 63) / 64) * p.B >= 256;
   const int ct = wide ? (p.Cout + 63) / 64 : (p.Cout + 31) / 32;
-  const long long nwg = (long long)ct * rg * p.B;
+  RowMap rm;
+  const long long units = ragged_units(p, 128, rg, rm);
+  if (units == 0) return nullptr;
+  const long long nwg = (long long)ct * units;
   if (nwg >= (1LL << 31)) return "conv_rows: grid too large";
   const dim3 grid((unsigned)nwg), block(256);
   // ring depth: a unit is 16 MFMAs of 64 cycles in fp32, 6 (bf16x3) or 2 (bf16) of 32 in the bf16 modes
   if (p.x3 == 0) {
-    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 0, 3, false>), grid, block, 0, s, p, rg, ct);
-    else hipLaunchKernelGGL((conv_rows_kernel<1, 0, 3, false>), grid, block, 0, s, p, rg, ct);
+    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 0, 3, false>), grid, block, 0, s, p, rg, ct, rm);
+    else hipLaunchKernelGGL((conv_rows_kernel<1, 0, 3, false>), grid, block, 0, s, p, rg, ct, rm);
   } else if (p.x3 == 1) {
-    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 1, 4, false>), grid, block, 0, s, p, rg, ct);
-    else hipLaunchKernelGGL((conv_rows_kernel<1, 1, 6, false>), grid, block, 0, s, p, rg, ct);
+    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 1, 4, false>), grid, block, 0, s, p, rg, ct, rm);
+    else hipLaunchKernelGGL((conv_rows_kernel<1, 1, 6, false>), grid, block, 0, s, p, rg, ct, rm);
   } else {
-    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 2, 4, false>), grid, block, 0, s, p, rg, ct);
-    else hipLaunchKernelGGL((conv_rows_kernel<1, 2, 6, false>), grid, block, 0, s, p, rg, ct);
+    if (wide) hipLaunchKernelGGL((conv_rows_kernel<2, 2, 4, false>), grid, block, 0, s, p, rg, ct, rm);
+    else hipLaunchKernelGGL((conv_rows_kernel<1, 2, 6, false>), grid, block, 0, s, p, rg, ct, rm);
   }
   return hipGetLastError() == hipSuccess ? nullptr : "conv_rows: launch failed";
 }

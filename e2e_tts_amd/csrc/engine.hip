@@ -133,7 +133,8 @@ struct e2etts_engine {
   long long st_emitted = 0;
   bool st_open = false, st_done = false;
   int ragged = 1;         // synthesize(): skip rows of shorter utterances that no valid output sample depends on
-  DevBuf actbuf;          // [2 + voc_stages + 1][B] int32 row limits
+  DevBuf actbuf;          // [5 + voc_stages][B] int32 row limits: decoder, mel_linear / postnet, vocoder stage 0 .. voc_stages, encoder (unused on the
+                          // device: lens32 serves), variance predictors
   std::vector<int32_t> h_act;  // the same limits on the host, same layout (valid for the call that computed them): the launchers build
                                // their compact grids from them (kernels.h: RowMap)
   double rag_frac_dec = 1.0, rag_frac_post = 1.0, rag_frac_voc = 1.0;  // fraction of the padded rows those limits leave (profile FLOP counts)
@@ -635,7 +636,7 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     {
       const double fl = 4.0 * B * c.n_head * (double)N * N * (H / c.n_head);
       ProfScope ps(e, sx ? "attention_x3" : "attention", fl, 4.0 * 4.0 * B * N * H);
-      KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, sx ? 1 : 0, e->stream));
+      KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, sx ? 1 : 0, e->stream, act_host));
     }
     // fc + residual (:238-239), LayerNorm eps 1e-5, masked_fill (:182-183)
     p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;
@@ -740,7 +741,8 @@ int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, float*
 
 // conv -> ReLU -> channel LayerNorm(eps 1e-12) [-> x (1 - mask)] stack + small Linear
 // (reference DurationPredictor U/layers.py:410-420, VariancePredictor :499-503)
-int predictor(e2etts_engine* e, const Predictor& pr, const float* x, float* out, const int32_t* mask_lens, int B, int L) {
+int predictor(e2etts_engine* e, const Predictor& pr, const float* x, float* out, const int32_t* mask_lens, int B, int L,
+              const int32_t* act = nullptr, const int32_t* act_host = nullptr, double act_frac = 1.0) {
   const int H = e->cfg.hidden;
   float* a = ptr<float>(e->p1);  // conv output
   float* b = ptr<float>(e->p2);  // LayerNorm output = next layer's input
@@ -749,6 +751,7 @@ int predictor(e2etts_engine* e, const Predictor& pr, const float* x, float* out,
   for (const PredLayer& l : pr.layers) {
     ConvParams p;
     p.B = B; p.T = L; p.in = in; p.w = l.w; p.bias = l.b; p.out = a; p.Cin = cin; p.Cout = pr.chans;
+    p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;
     p.KW = pr.kernel; p.pad = (pr.kernel - 1) / 2; p.act = ACT_RELU;
     RET(conv(e, p, 1.0, true));  // phoneme-level layer: conv_ksplit.hip at every batch size
     {
@@ -859,8 +862,33 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_embed(ptr<int64_t>(e->ids), e->emb, pos, x, B, L, H, c.n_symbols + 1, e->stream));
   }
+  // Ragged mode at the phoneme level (synthesize, lengths in HOST memory -- the compact grids are built from them).  FFT blocks and
+  // duration predictor: every consumer of a row >= len masks it (keys masked, LayerNorm kernels write zeros there), so their convolutions
+  // compute rows < len only.  Pitch / energy predictors are unmasked stacks of n convolutions of kernel k: the rows < len that the bucket
+  // kernel reads depend on rows < len + (n - 1)(k - 1)/2 of the layers before, so every layer computes that many (cap L).
+  const int32_t *act_enc = nullptr, *act_enc_h = nullptr, *act_var = nullptr, *act_var_h = nullptr;
+  double frac_enc = 1.0, frac_var = 1.0;
+  if (ragged && c.block_type == 0 && !is_device_pointer(lens)) {
+    RET(ensure(e, e->actbuf, (size_t)(5 + c.voc_stages) * B * 4));
+    e->h_act.resize((size_t)(5 + c.voc_stages) * B, 0);
+    int32_t* he = e->h_act.data() + (size_t)(3 + c.voc_stages) * B;
+    int32_t* hv = he + B;
+    const int add_var = (c.var_layers - 1) * ((c.var_kernel - 1) / 2);
+    double se = 0, sv = 0;
+    for (int b = 0; b < B; ++b) {
+      he[b] = (int32_t)std::min<long long>(std::max<long long>(lens[b], 0), L);   // lens_to_i32_kernel's clamp
+      hv[b] = (int32_t)std::min<long long>((long long)he[b] + add_var, L);        // act_rows_kernel's arithmetic
+      se += he[b];
+      sv += hv[b];
+    }
+    int32_t* dv = ptr<int32_t>(e->actbuf) + (size_t)(4 + c.voc_stages) * B;
+    KCHK(e, launch_act_rows(tl, dv, B, add_var, 1, L, e->stream));
+    act_enc = tl; act_enc_h = he; act_var = dv; act_var_h = hv;
+    frac_enc = se / ((double)B * L);
+    frac_var = sv / ((double)B * L);
+  }
   if (c.block_type == 1) RET(conformer_stack(e, e->cf_enc, x, ptr<float>(e->xb), tl, B, L, false));
-  else RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L, false, nullptr, 1.0, true));  // encoder: always exact fp32, K-split kernel
+  else RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L, false, act_enc, frac_enc, true, act_enc_h));  // encoder: always exact fp32, K-split kernel
   HIPCHK(e, hipMemcpyAsync(e->encout.p, x, BL * H * 4, hipMemcpyDeviceToDevice, e->stream));
 
   // Variance adaptor, inference branch (U/layers.py:195-258)
@@ -870,7 +898,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_add_speaker(xs, e->spk_emb, ptr<int64_t>(e->spk), n_spk_ids, c.n_speakers, B, L, H, e->stream));
   }
-  RET(predictor(e, e->dur, xs, ptr<float>(e->logd), tl, B, L));
+  RET(predictor(e, e->dur, xs, ptr<float>(e->logd), tl, B, L, act_enc, act_enc_h, frac_enc));
   {
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_duration(ptr<float>(e->logd), d_control, ptr<float>(e->durf), ptr<int32_t>(e->cum),
@@ -885,12 +913,12 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->pitch.alpha, xp, B, L, H, e->stream));
   }
-  RET(predictor(e, e->pitch, xp, ptr<float>(e->ppred), nullptr, B, L));
+  RET(predictor(e, e->pitch, xp, ptr<float>(e->ppred), nullptr, B, L, act_var, act_var_h, frac_var));
   {
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->energy.alpha, xp, B, L, H, e->stream));
   }
-  RET(predictor(e, e->energy, xp, ptr<float>(e->epred), nullptr, B, L));
+  RET(predictor(e, e->energy, xp, ptr<float>(e->epred), nullptr, B, L, act_var, act_var_h, frac_var));
   {
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_variance_embed(xs, ptr<float>(e->ppred), ptr<float>(e->epred), p_control, e_control, c.f0_mean, c.f0_std,
@@ -932,7 +960,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   // < mel_len + halo + 2 * postnet_layers; rows beyond hold stale finite values that no valid sample depends on.
   const int32_t *act_dec = nullptr, *act_post = nullptr, *act_dec_h = nullptr, *act_post_h = nullptr;
   if (ragged) {
-    RET(ensure(e, e->actbuf, (size_t)(3 + c.voc_stages) * B * 4));
+    RET(ensure(e, e->actbuf, (size_t)(5 + c.voc_stages) * B * 4));
     int32_t* ab = ptr<int32_t>(e->actbuf);
     const int halo = vocoder_halo_frames(c);
     KCHK(e, launch_act_rows(ml, ab, B, 0, 1, T, e->stream));
@@ -941,7 +969,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     act_post = ab + B;
     double sd = 0, sp = 0, sv = 0;  // the same limits on the host (mel lengths are in e->h_mel since the sync above)
     const long long add_post = halo + 2 * c.postnet_layers * ((c.postnet_kernel - 1) / 2);
-    e->h_act.assign((size_t)(3 + c.voc_stages) * B, 0);
+    e->h_act.resize((size_t)(5 + c.voc_stages) * B, 0);
     for (int b = 0; b < B; ++b) {
       const long long m32 = std::min<long long>(e->h_mel[b], 0x7fffffffLL);  // what duration_kernel wrote to mel32 (act_rows_kernel's input)
       e->h_act[b] = (int32_t)std::min<long long>(m32, T);
@@ -1028,10 +1056,10 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   const int32_t* act_stage[E2ETTS_MAX_STAGES + 1] = {nullptr};
   const int32_t* act_stage_h[E2ETTS_MAX_STAGES + 1] = {nullptr};  // the same limits in host memory (compact grids), when the caller has the lengths there
   if (ragged_lens) {
-    RET(ensure(e, e->actbuf, (size_t)(3 + c.voc_stages) * B * 4));
+    RET(ensure(e, e->actbuf, (size_t)(5 + c.voc_stages) * B * 4));
     int32_t* ab = ptr<int32_t>(e->actbuf) + 2 * B;
     const int halo = vocoder_halo_frames(c);
-    if (ragged_lens_host) e->h_act.resize((size_t)(3 + c.voc_stages) * B, 0);
+    if (ragged_lens_host) e->h_act.resize((size_t)(5 + c.voc_stages) * B, 0);
     long long rate = 1;
     for (int i = 0; i <= c.voc_stages; ++i) {
       KCHK(e, launch_act_rows(ragged_lens, ab + (size_t)i * B, B, halo, (int)rate, (long long)T * rate, e->stream));

@@ -64,6 +64,15 @@ int main(int argc, char** argv) {
     printf("few=%d half=%d\n", tile_few_rows(B, T, Cout) ? 1 : 0, tile_half_rows(B, T, Cout) ? 1 : 0);
     return 0;
   }
-  fprintf(stderr, "usage: host_logic_test blob|config <file> | tiles B T Cout\n");
+  if (argc >= 5 && !strcmp(argv[1], "ragged")) {  // ragged T Cout rows_0 rows_1 ...: the counts a ragged launch is sized on, and its tile choice
+    const int T = atoi(argv[2]), Cout = atoi(argv[3]);
+    std::vector<int32_t> rows;
+    for (int i = 4; i < argc; ++i) rows.push_back((int32_t)atoll(argv[i]));
+    long long t128 = 0, n = 0;
+    ragged_counts(rows.data(), (int)rows.size(), T, Cout, &t128, &n);
+    printf("t128=%lld rows=%lld few=%d half=%d\n", t128, n, tile_few_rows_n(t128, n, Cout) ? 1 : 0, tile_half_rows_n(t128, n, Cout) ? 1 : 0);
+    return 0;
+  }
+  fprintf(stderr, "usage: host_logic_test blob|config <file> | tiles B T Cout | ragged T Cout rows...\n");
   return 2;
 }

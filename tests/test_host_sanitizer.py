@@ -136,3 +136,17 @@ def test_tile_choice(harness):
     assert run(harness, "tiles", 32, 768, 64) == "few=0 half=0"
     for args in ((0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF), (1, 1, 65), (4096, 1 << 20, 8192)):
         assert run(harness, "tiles", *args).startswith("few=")
+
+
+def test_ragged_counts(harness):
+    """The counts a ragged launch is sized on (host_logic.h: ragged_counts, fed from ConvParams::act_rows_host): rows are clamped to
+    [0, T] per utterance, tiles counted per utterance (each ends in a partial tile), and the tile choice follows the REAL counts -- the
+    mixed-length decoder Linear takes the 64-row tile where its padded shape (32 x 1200) would not."""
+    assert run(harness, "ragged", 1200, 384, 240, 1200, 600) == "t128=51 rows=2040 few=1 half=0"          # (2 + 10 + 5) row tiles x 3 column tiles
+    assert run(harness, "ragged", 1200, 384, -5, 5000, 0) == "t128=30 rows=1200 few=1 half=0"            # clamped: 0, T, 0
+    lens = [6 * n for n in (40, 45, 50, 56, 61, 66, 71, 76, 81, 86, 92, 97, 102, 107, 112, 117, 123, 128, 133, 138, 143, 148, 154, 159, 164,
+                            169, 174, 179, 184, 190, 195, 200)]
+    out = run(harness, "ragged", 1200, 1024, *lens)
+    assert out.startswith("t128=") and out.endswith("few=0 half=1"), out
+    assert run(harness, "tiles", 32, 1200, 1024) == "few=0 half=0"
+    assert run(harness, "ragged", 0x7FFFFFFF, 0x7FFFFFFF, *([0x7FFFFFFF] * 64)).startswith("t128=")

@@ -112,7 +112,7 @@ struct e2etts_engine {
   DevBuf ids, lens64, lens32, spk, xa, xb, xs, xp, tmp, qkv, att, hid, p1, p2;
   DevBuf relps;  // Conformer: unshifted position scores [B, n_head, N, ceil4(N)]
   DevBuf logd, durf, cum, mel64, mel32, posbuf, ppred, epred, pidx, eidx;
-  DevBuf dx, dxb, mel, melpost, pn1, pn2, encout;
+  DevBuf dx, dxb, mel, melpost, pn1, pn2;
   DevBuf melin, v0, v1, v2, v3, wav, pcm;
   // small batches: the ResBlocks of a vocoder stage run side by side, ResBlock j > 0 on side stream j - 1 with buffers of its own
   // (stage sum, two ping-pong buffers); created on first use
@@ -133,6 +133,7 @@ struct e2etts_engine {
   long long st_emitted = 0;
   bool st_open = false, st_done = false;
   int ragged = 1;         // synthesize(): skip rows of shorter utterances that no valid output sample depends on
+  bool rag_short = false; // the last acoustic pass had an utterance shorter than T (else ragged mode has nothing to skip)
   DevBuf actbuf;          // [5 + voc_stages][B] int32 row limits: decoder, mel_linear / postnet, vocoder stage 0 .. voc_stages, encoder (unused on the
                           // device: lens32 serves), variance predictors
   std::vector<int32_t> h_act;  // the same limits on the host, same layout (valid for the call that computed them): the launchers build
@@ -845,7 +846,6 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   RET(ensure(e, e->epred, BL * 4));
   RET(ensure(e, e->pidx, BL * 4));
   RET(ensure(e, e->eidx, BL * 4));
-  RET(ensure(e, e->encout, BL * H * 4));
 
   e->have_acoustic = false;
   RET(copy_in(e, e->ids.p, ids, BL * 8));
@@ -868,7 +868,11 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   // kernel reads depend on rows < len + (n - 1)(k - 1)/2 of the layers before, so every layer computes that many (cap L).
   const int32_t *act_enc = nullptr, *act_enc_h = nullptr, *act_var = nullptr, *act_var_h = nullptr;
   double frac_enc = 1.0, frac_var = 1.0;
-  if (ragged && c.block_type == 0 && !is_device_pointer(lens)) {
+  bool enc_short = false;  // some utterance is shorter than the padded length (else every limit equals L: nothing to skip, and the
+                           // launches keep their plain grids -- the B = 1 latency path pays no act_rows kernels)
+  if (ragged && c.block_type == 0 && !is_device_pointer(lens))
+    for (int b = 0; b < B; ++b) enc_short = enc_short || lens[b] < L;
+  if (enc_short) {
     RET(ensure(e, e->actbuf, (size_t)(5 + c.voc_stages) * B * 4));
     e->h_act.resize((size_t)(5 + c.voc_stages) * B, 0);
     int32_t* he = e->h_act.data() + (size_t)(3 + c.voc_stages) * B;
@@ -889,14 +893,12 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   }
   if (c.block_type == 1) RET(conformer_stack(e, e->cf_enc, x, ptr<float>(e->xb), tl, B, L, false));
   else RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L, false, act_enc, frac_enc, true, act_enc_h));  // encoder: always exact fp32, K-split kernel
-  HIPCHK(e, hipMemcpyAsync(e->encout.p, x, BL * H * 4, hipMemcpyDeviceToDevice, e->stream));
 
   // Variance adaptor, inference branch (U/layers.py:195-258)
   float* xs = ptr<float>(e->xs);
-  HIPCHK(e, hipMemcpyAsync(xs, x, BL * H * 4, hipMemcpyDeviceToDevice, e->stream));
   {
     ProfScope ps(e, "misc", 0, 0);
-    KCHK(e, launch_add_speaker(xs, e->spk_emb, ptr<int64_t>(e->spk), n_spk_ids, c.n_speakers, B, L, H, e->stream));
+    KCHK(e, launch_add_speaker(x, xs, e->spk_emb, ptr<int64_t>(e->spk), n_spk_ids, c.n_speakers, B, L, H, e->stream));
   }
   RET(predictor(e, e->dur, xs, ptr<float>(e->logd), tl, B, L, act_enc, act_enc_h, frac_enc));
   {
@@ -916,7 +918,8 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   RET(predictor(e, e->pitch, xp, ptr<float>(e->ppred), nullptr, B, L, act_var, act_var_h, frac_var));
   {
     ProfScope ps(e, "misc", 0, 0);
-    KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->energy.alpha, xp, B, L, H, e->stream));
+    KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->energy.alpha, xp, B, L, H, e->stream,
+                                 false));  // the positions depend on xs alone: the pitch predictor's pass left them in posbuf
   }
   RET(predictor(e, e->energy, xp, ptr<float>(e->epred), nullptr, B, L, act_var, act_var_h, frac_var));
   {
@@ -959,7 +962,10 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   // mel_linear / postnet are unmasked and the vocoder reads `halo` frames past the end, so they compute rows
   // < mel_len + halo + 2 * postnet_layers; rows beyond hold stale finite values that no valid sample depends on.
   const int32_t *act_dec = nullptr, *act_post = nullptr, *act_dec_h = nullptr, *act_post_h = nullptr;
-  if (ragged) {
+  // (equal lengths -- B = 1, a fixed-length batch --: every limit would equal T; nothing is skipped and no act_rows kernel is launched)
+  e->rag_short = false;
+  for (int b = 0; b < B; ++b) e->rag_short = e->rag_short || e->h_mel[b] < T;
+  if (ragged && e->rag_short) {
     RET(ensure(e, e->actbuf, (size_t)(5 + c.voc_stages) * B * 4));
     int32_t* ab = ptr<int32_t>(e->actbuf);
     const int halo = vocoder_halo_frames(c);
@@ -1240,9 +1246,12 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       if (aside) HIPCHK(e, hipEventRecord(e->ev_join[j - 1], e->stream));
     }
     if (conc) {  // join: S = ((S_0 + S_1) + S_2 ...) / num_kernels, the accumulating epilogues' order
-      for (int j = 1; j < nk; ++j) {
-        HIPCHK(e, hipStreamWaitEvent(main_stream, e->ev_join[j - 1], 0));
-        KCHK(e, launch_accum_div(S_main, ptr<float>(e->vside[j - 1][0]), (long long)B * n * co, j == nk - 1 ? (float)nk : 1.0f, main_stream));
+      for (int j = 1; j < nk; ++j) HIPCHK(e, hipStreamWaitEvent(main_stream, e->ev_join[j - 1], 0));
+      for (int j = 1; j < nk; j += 2) {  // two side sums per pass: (S + S_j) + S_j+1, the same additions in the same order
+        const bool two = j + 1 < nk;
+        const bool closes = (two ? j + 1 : j) == nk - 1;
+        KCHK(e, launch_accum_div(S_main, ptr<float>(e->vside[j - 1][0]), (long long)B * n * co, closes ? (float)nk : 1.0f, main_stream,
+                                 two ? ptr<float>(e->vside[j][0]) : nullptr));
       }
       drain.armed = false;  // every side stream's work is now ordered before the main stream's next launch
     }
@@ -1496,7 +1505,7 @@ int e2etts_fetch_tap(e2etts_engine* e, const char* which, float* out, size_t n_f
     return E2ETTS_OK;
   }
   if (!e->have_acoustic) return e->fail(E2ETTS_ESTATE, "no acoustic result resident");
-  if (!strcmp(which, "enc_out")) { src = e->encout.p; n = (size_t)e->last_B * e->last_L * e->cfg.hidden; }
+  if (!strcmp(which, "enc_out")) { src = e->xa.p;  /* the encoder's output stays in its own buffer: nothing later in the pass writes it */ n = (size_t)e->last_B * e->last_L * e->cfg.hidden; }
   else if (!strcmp(which, "dec_out")) { src = e->dx.p; n = (size_t)e->last_B * e->last_T * e->cfg.hidden; }
   else return e->fail(E2ETTS_EKEY, "unknown tap '%s'", which);
   if (n_floats != n) return e->fail(E2ETTS_EINVAL, "tap '%s' holds %zu floats, caller asked for %zu", which, n, n_floats);
@@ -1551,8 +1560,9 @@ int e2etts_synthesize(e2etts_engine* e, const int64_t* ids, const int64_t* lens,
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(e, hipSetDevice(e->device));
   if (B > 4096) return e->fail(E2ETTS_EINVAL, "B > 4096");
-  const bool ragged = e->ragged != 0;
+  bool ragged = e->ragged != 0;
   RET(acoustic_impl(e, ids, lens, B, L, speaker, n_spk_ids, d_control, p_control, e_control, ragged));
+  ragged = ragged && e->rag_short;
   if (T_out) *T_out = e->last_T;
   RET(vocoder_impl(e, ptr<float>(e->melpost), B, e->last_T, false, true, ragged ? ptr<int32_t>(e->mel32) : nullptr, ragged ? e->h_mel : nullptr));
   if (mel_lens_out) RET(copy_out(e, mel_lens_out, e->mel64.p, (size_t)B * 8));

@@ -91,13 +91,13 @@ const char* launch_layernorm(const float* x, float* y, const float* gamma, const
 // x[b, l, :] = emb[ids[b, l], :] + pos[l, :]
 const char* launch_embed(const int64_t* ids, const float* emb, const float* pos, float* x, int B, int L, int H,
                          int n_rows, hipStream_t s);
-// x[b, l, :] += spk[speaker[b or 0], :]
-const char* launch_add_speaker(float* x, const float* spk, const int64_t* speaker, int n_spk_ids, int n_speakers,
+// x[b, l, :] = xin[b, l, :] + spk[speaker[b or 0], :]   (xin may be x)
+const char* launch_add_speaker(const float* xin, float* x, const float* spk, const int64_t* speaker, int n_spk_ids, int n_speakers,
                                int B, int L, int H, hipStream_t s);
 // y = x + alpha[0] * table[pos(b, l)], pos = running count of x[b, l, 0] != 0 (0 where it is 0)
-// (posbuf: [B, L] int32 scratch)
+// (posbuf: [B, L] int32 scratch; compute_positions = false reuses what an earlier call on the same x left there)
 const char* launch_var_positions(const float* x, int32_t* posbuf, const float* table, int table_rows, const float* alpha,
-                                 float* y, int B, int L, int H, hipStream_t s);
+                                 float* y, int B, int L, int H, hipStream_t s, bool compute_positions = true);
 // out[row, o] = dot(x[row, :], w[o, :]) + b[o], o < O <= 2; rows >= lens[b] -> 0 when lens != null
 const char* launch_rowdot(const float* x, const float* w, const float* b, float* out, const int32_t* lens, int B, int L,
                           int C, int O, hipStream_t s);
@@ -115,8 +115,8 @@ const char* launch_length_regulate(const float* x, const int32_t* cum, const int
                                    float* y, int B, int L, int T, int H, hipStream_t s);
 // out[b] = min(cap, (lens[b] + add) * mul): rows a layer has to compute for utterance b in ragged mode
 const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s);
-// S = (S + Sj) [/ div] over n floats (n % 4 == 0): joins the sums of ResBlocks run on side streams
-const char* launch_accum_div(float* S, const float* Sj, long long n, float div, hipStream_t s);
+// S = (S + Sj) [+ Sk] [/ div] over n floats (n % 4 == 0): joins the sums of ResBlocks run on side streams
+const char* launch_accum_div(float* S, const float* Sj, long long n, float div, hipStream_t s, const float* Sk = nullptr);
 // [B, C, T] -> [B, T, C]
 // One (conv k, dilation d -> leaky ReLU -> conv k, dilation 1 -> + x) pair of a HiFi-GAN ResBlock1 in one launch
 // (resblock_pair.hip): out = c2(lrelu(c1(lrelu(x)) + b1)) + b2 + x, optionally (out_old + that) / out_div.

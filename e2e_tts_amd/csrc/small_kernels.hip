@@ -85,16 +85,17 @@ __global__ void embed_kernel(const int64_t* __restrict__ ids, const float* __res
   }
 }
 
-__global__ void add_speaker_kernel(float* __restrict__ x, const float* __restrict__ spk, const int64_t* __restrict__ speaker,
-                                   int n_spk_ids, int n_speakers, int L, int H) {
+__global__ void add_speaker_kernel(const float* __restrict__ xin, float* __restrict__ x, const float* __restrict__ spk,
+                                   const int64_t* __restrict__ speaker, int n_spk_ids, int n_speakers, int L, int H) {
   const int row = blockIdx.x;
   const int b = row / L;
   long long sid = speaker[n_spk_ids == 1 ? 0 : b];
   sid = sid < 0 ? 0 : (sid >= n_speakers ? n_speakers - 1 : sid);
   const float4* e = reinterpret_cast<const float4*>(spk + sid * H);
   float4* o = reinterpret_cast<float4*>(x + (long long)row * H);
+  const float4* in = reinterpret_cast<const float4*>(xin + (long long)row * H);
   for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
-    const float4 a = o[i], c = e[i];
+    const float4 a = in[i], c = e[i];
     o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
   }
 }
@@ -608,11 +609,11 @@ const char* launch_embed(const int64_t* ids, const float* emb, const float* pos,
   return CHECK_LAUNCH("embed");
 }
 
-const char* launch_add_speaker(float* x, const float* spk, const int64_t* speaker, int n_spk_ids, int n_speakers,
+const char* launch_add_speaker(const float* xin, float* x, const float* spk, const int64_t* speaker, int n_spk_ids, int n_speakers,
                                int B, int L, int H, hipStream_t s) {
-  if (!x || !spk || !speaker) return "add_speaker: null pointer";
+  if (!xin || !x || !spk || !speaker) return "add_speaker: null pointer";
   if (n_spk_ids != 1 && n_spk_ids != B) return "add_speaker: speaker must have 1 or B entries";
-  hipLaunchKernelGGL(add_speaker_kernel, dim3(B * L), dim3(128), 0, s, x, spk, speaker, n_spk_ids, n_speakers, L, H);
+  hipLaunchKernelGGL(add_speaker_kernel, dim3(B * L), dim3(128), 0, s, xin, x, spk, speaker, n_spk_ids, n_speakers, L, H);
   return CHECK_LAUNCH("add_speaker");
 }
 
@@ -657,20 +658,24 @@ const char* launch_length_regulate(const float* x, const int32_t* cum, const int
 
 // S = (S + Sj) [/ div]: joins the stage sums of ResBlocks that ran side by side (engine.hip, small batches); the operations the
 // accumulating epilogues of conv_gemm / resblock_pair / resblock_chain perform, in their order.
-__global__ void accum_div_kernel(float* __restrict__ S, const float* __restrict__ Sj, long long n4, float div) {
+__global__ void accum_div_kernel(float* __restrict__ S, const float* __restrict__ Sj, const float* __restrict__ Sk, long long n4, float div) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   float4 a = reinterpret_cast<const float4*>(S)[i];
   const float4 b = reinterpret_cast<const float4*>(Sj)[i];
   a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  if (Sk) {  // (S + Sj) + Sk: the order of two passes, in one
+    const float4 c = reinterpret_cast<const float4*>(Sk)[i];
+    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+  }
   if (div != 1.0f) { a.x = a.x / div; a.y = a.y / div; a.z = a.z / div; a.w = a.w / div; }
   reinterpret_cast<float4*>(S)[i] = a;
 }
 
-const char* launch_accum_div(float* S, const float* Sj, long long n, float div, hipStream_t s) {
+const char* launch_accum_div(float* S, const float* Sj, long long n, float div, hipStream_t s, const float* Sk) {
   if (!S || !Sj || n <= 0 || (n & 3)) return "accum_div: bad arguments";
   const long long n4 = n / 4;
-  hipLaunchKernelGGL(accum_div_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, S, Sj, n4, div);
+  hipLaunchKernelGGL(accum_div_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, S, Sj, Sk, n4, div);
   return hipGetLastError() == hipSuccess ? nullptr : "accum_div: launch failed";
 }
 
@@ -777,10 +782,10 @@ const char* launch_conv_post(const float* x, const float* w, const float* bias, 
 }
 
 const char* launch_var_positions(const float* x, int32_t* posbuf, const float* table, int table_rows, const float* alpha,
-                                  float* y, int B, int L, int H, hipStream_t s) {
+                                  float* y, int B, int L, int H, hipStream_t s, bool compute_positions) {
   if (!x || !posbuf || !table || !alpha || !y) return "var_positions: null pointer";
   if (L + 1 > table_rows) return "var_positions: sequence longer than the shipped position table";
-  hipLaunchKernelGGL(var_positions_kernel, dim3(B), dim3(64), 0, s, x, posbuf, L, H);
+  if (compute_positions) hipLaunchKernelGGL(var_positions_kernel, dim3(B), dim3(64), 0, s, x, posbuf, L, H);
   hipLaunchKernelGGL(var_pos_add_kernel, dim3(B * L), dim3(128), 0, s, x, posbuf, table, table_rows, alpha, y, H);
   return CHECK_LAUNCH("var_positions");
 }

@@ -403,8 +403,8 @@ def case_g2p():
     symbols = list(ref_sym.symbols)
     sym2id = {s: i for i, s in enumerate(symbols)}
     words = [w for w in ref_g2p.vn_words]
-    rng = np.random.Generator(np.random.PCG64(9))
-    pick = sorted(set(rng.choice(len(words), size=1500, replace=False).tolist()))
+    # every word of dict/fix_words.txt the reference's converter accepts (17 977 entries; round 2 sampled 1 500)
+    pick = range(len(words))
     sample, phon = [], []
     skipped = 0
     for i in pick:
@@ -462,6 +462,16 @@ def case_hifigan48k(models):
         assert wav.shape == (B, T * 512), wav.shape
         arrays[f"{tag}.mel"] = mel
         arrays[f"{tag}.wav"] = wav.copy()
+        # The reference's own class run in bfloat16 (module.bfloat16() on a bf16 mel: weight_g / weight_v, every activation and every
+        # layer output in bf16, torch-CPU kernels): what "config 5's arithmetic" is when the REFERENCE does it.  Its distance from the
+        # reference's fp32 output is the yardstick for the engine's plain-bf16 mode (tests/test_gpu_longform.py).
+        import copy
+        v16 = copy.deepcopy(v).bfloat16()
+        wav16 = v16(torch.from_numpy(np.ascontiguousarray(mel.transpose(0, 2, 1))).bfloat16()).squeeze(1).float().numpy()
+        assert wav16.shape == wav.shape and np.isfinite(wav16).all()
+        arrays[f"{tag}.wav_ref_bf16"] = wav16.copy()
+        arrays[f"{tag}.ref_bf16_mean_l1"] = np.float64(np.abs(wav16.astype(np.float64) - wav.astype(np.float64)).mean())
+        print(f"    {tag}: reference in bf16 vs reference in fp32: wav mean-L1 {float(arrays[f'{tag}.ref_bf16_mean_l1']):.3e}", flush=True)
         arrays[f"{tag}.width"] = np.int64(width)
         arrays[f"{tag}.weight_seed"] = np.int64(wseed)
         print(f"    {tag}: wav {wav.shape} |wav| mean {np.abs(wav).mean():.3e}", flush=True)

@@ -13,7 +13,10 @@ def test_symbol_table_matches_reference():
 
 
 def test_syllables_match_reference():
+    """Every entry of the reference's dict/fix_words.txt (17 978 words: SURVEY.md 8(f) #1 asks for the whole dictionary), converted by the
+    reference's own vi_convert when the fixture was made (oracle/make_goldens.py: case_g2p)."""
     g = load_golden("g2p")
+    assert len(g["words"]) >= 17900 and len(set(g["words"].tolist())) == len(g["words"])
     bad = [(w, " ".join(g2p.vi_convert(str(w))), str(p)) for w, p in zip(g["words"], g["phonemes"])
            if " ".join(g2p.vi_convert(str(w))) != str(p)]
     assert not bad, bad[:10]

@@ -40,7 +40,9 @@ def test_48k_vocoder_matches_oracle_in_all_precisions():
     ref = orc.VocoderOracle(voc, cfg).forward(mel.transpose(0, 2, 1))[:, 0]
     assert ref.shape == (2, 90 * 512)
     errs = {}
-    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 6e-4)):   # plain bf16: see test_48k_vocoder_matches_reference_fixture
+    # plain bf16: no farther from fp32 than the REFERENCE's own bf16 run of this width (5.9e-4, fixture hifigan_48k w64:
+    # test_48k_vocoder_matches_reference_fixture pins it on the fixture's mel; this random mel has the same statistics)
+    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 5.9e-4)):
         eng.set_precision(prec)
         wav, _ = eng.vocoder(mel, 2, 90, channels_first=False)
         errs[prec] = mean_l1(wav, ref)
@@ -53,10 +55,8 @@ def test_48k_vocoder_matches_oracle_in_all_precisions():
 def test_48k_vocoder_matches_reference_fixture(tag):
     """The 48 kHz generator against the reference's own HifiGan class (fixture hifigan_48k; V/generator.py:14-53 instantiated with
     upsample_rates [8, 8, 4, 2] / kernels [16, 16, 8, 4]) at widths 64 and 512.  fp32 and split precision meet the fp32 bar.  Plain
-    bf16 -- config 5's arithmetic -- rounds every operand to 8 significant bits (relative 2^-9 per product term); SURVEY.md 6 measured
-    torch's bf16 vocoder at wav mean-L1 1.2e-4 against fp32, and the random-init generators here measure 3.3e-4 (width 64) and 4.0e-4
-    (width 512) against the reference's fp32 output (fp32: 4e-8 / 9e-8, bf16x3: 6e-7 / 8e-7): the stated bar is 6e-4 mean-L1 = 1.5 x the
-    measured value (|wav| mean is 5e-2..7e-2, so that is ~1 % of the signal); the measured value is printed."""
+    bf16 -- config 5's arithmetic -- rounds every operand to 8 significant bits (relative 2^-9 per product term); it is pinned against
+    the reference's own class run in bfloat16 (below)."""
     from conftest import load_golden
     g = load_golden("hifigan_48k")
     cfg = cfg48(int(g[f"{tag}.width"]))
@@ -64,7 +64,14 @@ def test_48k_vocoder_matches_reference_fixture(tag):
     mel, ref = g[f"{tag}.mel"], g[f"{tag}.wav"]
     B, T = mel.shape[0], mel.shape[1]
     errs = {}
-    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 6e-4)):
+    # Plain bf16 (round 3): the yardstick is the REFERENCE ITSELF run in bfloat16 -- its HifiGan class cast with
+    # .bfloat16() on a bf16 mel (fixture keys wav_ref_bf16 / ref_bf16_mean_l1: 5.9e-4 at width 64, 8.6e-4 at width 512 against its own
+    # fp32 output).  The engine's bf16 mode rounds the OPERANDS of every convolution to bf16 but keeps activations, residual sums and
+    # accumulators in fp32, so it must land no farther from the reference's fp32 output than the reference's bf16 run does (factor 1.0,
+    # stated; measured 3.3e-4 / 4.0e-4 = 0.56 x / 0.46 x), and within 1.5 x that distance of the reference's bf16 output itself.
+    ref_bf16, ref_bf16_err = g[f"{tag}.wav_ref_bf16"], float(g[f"{tag}.ref_bf16_mean_l1"])
+    assert abs(mean_l1(ref_bf16, ref) - ref_bf16_err) < 1e-9
+    for prec, bar in (("fp32", 1e-5), ("bf16x3", 1e-5), ("bf16", 1.0 * ref_bf16_err)):
         eng.set_precision(prec)
         wav, pcm = eng.vocoder(mel, B, T, channels_first=False, pcm=True)
         errs[prec] = mean_l1(wav, ref)
@@ -72,7 +79,10 @@ def test_48k_vocoder_matches_reference_fixture(tag):
         if prec != "bf16":
             lsb = np.abs(pcm.astype(np.int32) - (ref * np.float32(32768.0)).astype(np.int16).astype(np.int32)) <= 1
             assert lsb.mean() >= 0.999, (prec, lsb.mean())
-    print(f"48k {tag} mean-L1 vs the reference: {errs}")
+        else:
+            errs["bf16_vs_ref_bf16"] = mean_l1(wav, ref_bf16)
+            assert errs["bf16_vs_ref_bf16"] < 1.5 * ref_bf16_err, errs
+    print(f"48k {tag} mean-L1 vs the reference: {errs}; the reference in bf16 vs itself in fp32: {ref_bf16_err:.3e}")
     assert errs["fp32"] <= errs["bf16x3"] < errs["bf16"]
 
 
@@ -126,4 +136,6 @@ def test_long_form_60s_stream_bf16():
     exact, _ = eng.vocoder(mel, 1, T, channels_first=False)
     err = mean_l1(out, exact)
     print(f"long-form bf16 vs bf16x3: mean-L1 {err:.3e}")
-    assert err < 6e-4   # the stated plain-bf16 bar (test_48k_vocoder_matches_reference_fixture); measured 3.2e-4
+    # the reference's own bf16 run of this generator (width 512) lies 8.6e-4 from its fp32 output (fixture hifigan_48k w512,
+    # test_48k_vocoder_matches_reference_fixture); the engine's bf16 mode must stay inside that distance.  Measured 3.2e-4.
+    assert err < 8.6e-4

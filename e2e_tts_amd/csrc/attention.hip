@@ -20,6 +20,8 @@
 namespace e2etts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -30,6 +32,14 @@ namespace {
 // (s_waitcnt vmcnt(0)) -- including the next chunk's K / V rows the split kernels have just requested, which is the round trip the
 // request was issued early to hide.  LDS writes and reads are counted by lgkmcnt alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDS written by other lanes of THIS wavefront: order later reads behind the writes (and later writes behind earlier reads) without a
+// workgroup barrier.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // (utterance b, head, query block qblk) of this workgroup.  Padded grid: (x, y, z) = (query block, head, utterance).  Compact grid of a
 // ragged batch whose lengths the host knows (kernels.h: RowMap): 1-D, utterance b owns ceil(len_b / rows) x n_head consecutive blocks,
@@ -362,35 +372,66 @@ __global__ __launch_bounds__(QT * 128, 2) void attention_split_kernel(const floa
 
 // ---- Conformer: relative-position attention (reference U/blocks/conformer.py:399-440), fp32.  Same flash-style structure and MFMA
 // orientation as attention_kernel; differences: u_bias is added to the query fragments; nothing is masked (the block calls the module
-// without a mask, :252, so padded keys take part and padded queries are computed); the score gets the shifted position term from the
-// materialised (q + v) . P matrix `ps` before it is divided by sqrt(d_model) (:384, :418).  DK need not be a multiple of 32: the
-// P . V product runs on ceil(DK / 32) tiles with V zero-padded in LDS.
+// without a mask, :252, so padded keys take part and padded queries are computed); the score gets the SHIFTED position term before it
+// is divided by sqrt(d_model) (:384, :418).  DK need not be a multiple of 32: the P . V product runs on ceil(DK / 32) tiles with V
+// zero-padded in LDS.
+//
+// The position term, computed HERE (round 3; rounds 1-2 materialised the unshifted scores (q + v) . P^T as a [B, heads, N, N] tensor --
+// 604 MB at B = 32, T = 768 -- with one GEMM per head and gathered the shifted entries 4 bytes at a time).  _relative_shift (:432-440)
+// is the Transformer-XL reshape applied to a non-causal score matrix; index for index it reads
+//     (i, j <= i)     -> (q_i + v)     . P[N - 1 - i + j]
+//     (i, j == i + 1) -> 0
+//     (i, j >= i + 2) -> (q_{i+1} + v) . P[j - i - 2]
+// i.e. the P row is a function of j - i alone.  For a tile of 32 queries i0 + a and 32 keys j0 + c the rows needed are a BAND of 63
+// consecutive rows of P, indexed by t = c - a + 31: the wavefront stages that band (64 rows) in its own LDS region, computes
+// G^T[t][a] = P[band row t] . (q_a + v) with 2 x DK / 2 MFMAs -- the same orientation as S^T = K . Q^T -- and reads the entry each
+// (query, key) pair needs back through LDS with the skew t = c - a + 31.  Tiles below the diagonal take the first form only, tiles
+// above it the third (with the NEXT query's vector, a second set of fragments), the diagonal tile computes both bands and selects.
 template <int DK>
-__global__ __launch_bounds__(256) void rel_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ ps, int ldp,
-                                                            const float* __restrict__ ub, float* __restrict__ out, int N, int H,
-                                                            float temperature) {
+__global__ __launch_bounds__(256, 2) void rel_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ pos, int pos_rows,
+                                                               const float* __restrict__ ub, const float* __restrict__ vb,
+                                                               float* __restrict__ out, int N, int H, float temperature) {
   static_assert(DK % 8 == 0, "head dim must be a multiple of 8");
   constexpr int DT = (DK + 31) / 32;
   constexpr int LDS_LD = DT * 32 + 4;
   constexpr int QQ = DK / 8;
+  constexpr int PLD = DK + 4;           // band row stride (floats): (DK + 4) / 4 is odd -> a ds_read_b128 of 16 rows covers the 64 banks once
+  constexpr int GLD = 34;               // G^T row stride: the skewed read (row c - a + 31, column a) then walks distinct banks
+  constexpr int NB4 = 32 * (DK / 4);    // float4 of one band tile (32 table rows)
+  constexpr int NPRE = (NB4 + 63) / 64; // ... per lane
   __shared__ __attribute__((aligned(16))) float Ks[32 * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Vs[32 * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Pb[4][32 * PLD];   // per wavefront: the 32 table rows of one band tile
+  __shared__ __attribute__((aligned(16))) float Gt[4][64 * GLD];   // per wavefront: G^T of the current band (two tiles)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y, n_head = gridDim.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int i0 = blockIdx.x * 128 + wave * 32;
   const int ld = 3 * H;
   const float* base = qkv + (long long)b * N * ld;
   const float* qp = base + head * DK;
   const float* kp = base + H + head * DK;
   const float* vp = base + 2 * H + head * DK;
-  const float* psb = ps + ((long long)b * n_head + head) * N * ldp;
+  const float* ph = pos + (long long)head * pos_rows * DK;   // this head's projected position table [pos_rows][DK]
+  float* const band = Pb[wave];
+  float* const gt = Gt[wave];
 
-  const int qi = min(q0 + li, N - 1);  // this lane's query (clamped: rows >= N are computed and dropped)
-  float4 qf[QQ];
+  const int qi = min(i0 + li, N - 1);  // this lane's query (clamped: rows >= N are computed and dropped)
+  // q + u (content term) and ONE set of position fragments: q + v while the chunks lie at or below the diagonal (j <= i), reloaded as
+  // q_{i+1} + v when the upper form starts at the diagonal tile (j >= i + 2) -- two sets at once cost 24 registers and spilled
+  float4 qf[QQ], qx[QQ];
+  auto load_qx = [&](const int row) __attribute__((always_inline)) {
+    const float* qr = qp + (row * ld + lh * 4);
+    const float* vr = vb + head * DK + lh * 4;
+#pragma unroll
+    for (int qq = 0; qq < QQ; ++qq) {
+      const float4 a = *reinterpret_cast<const float4*>(qr + qq * 8), v4 = *reinterpret_cast<const float4*>(vr + qq * 8);
+      qx[qq] = make_float4(a.x + v4.x, a.y + v4.y, a.z + v4.z, a.w + v4.w);
+    }
+  };
   {
-    const float* qr = qp + (long long)qi * ld + lh * 4;
+    const float* qr = qp + (qi * ld + lh * 4);
     const float* ur = ub + head * DK + lh * 4;
 #pragma unroll
     for (int qq = 0; qq < QQ; ++qq) {
@@ -398,6 +439,7 @@ __global__ __launch_bounds__(256) void rel_attention_kernel(const float* __restr
       qf[qq] = make_float4(a.x + u4.x, a.y + u4.y, a.z + u4.z, a.w + u4.w);
     }
   }
+  load_qx(qi);
   // zero the V padding columns once (they are never overwritten)
   if (DK % 32) {
     for (int i = tid; i < 32 * (DT * 32 - DK); i += 256) {
@@ -413,38 +455,115 @@ __global__ __launch_bounds__(256) void rel_attention_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  // The band SLIDES: the next key chunk's band is this one's shifted by 32 table rows, so its first G^T tile (t < 32) is this chunk's
+  // second one (t >= 32) -- P[row] . x does not depend on the chunk.  Per chunk ONE new tile of 32 table rows is staged and multiplied
+  // (both tiles only where a sequence starts: the first chunk, and the upper form at the diagonal), and its rows are requested one
+  // chunk ahead (`pre`), so their trip through L2 sits behind the previous chunk's arithmetic.
+  typedef f32x4v PRE_T;   // a native vector (float4 / uint4 are structs of unions: an array of them carried around the chunk loop stayed in scratch memory)
+  auto band_fetch = [&](PRE_T (&pre)[NPRE], const int row_start) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = min(lane + 64 * i, NB4 - 1);
+      const int r = idx / (DK / 4), c4 = (idx % (DK / 4)) * 4;
+      const int row = min(max(row_start + r, 0), pos_rows - 1);   // rows outside [0, N) feed entries nobody selects
+      pre[i] = *reinterpret_cast<const f32x4v*>(ph + row * DK + c4);
+    }
+  };
+  // G^T tile of the 32 table rows in `pre`: [t][a] = P[row_start + t] . x_a (32 x 32, the orientation of S^T = K . Q^T)
+  auto band_tile = [&](const PRE_T (&pre)[NPRE], const float4 (&x)[QQ]) __attribute__((always_inline)) -> f32x16 {
+    wave_lds_fence();   // the previous tile's fragment reads are complete in every lane
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < NB4) *reinterpret_cast<f32x4v*>(band + (idx / (DK / 4)) * PLD + (idx % (DK / 4)) * 4) = pre[i];
+    }
+    wave_lds_fence();
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = 0.f;
+    const float* pa = band + li * PLD + lh * 4;
+#pragma unroll
+    for (int qq = 0; qq < QQ; ++qq) {
+      const float4 a = *reinterpret_cast<const float4*>(pa + qq * 8);
+      g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, x[qq].x, g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, x[qq].y, g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, x[qq].z, g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, x[qq].w, g, 0, 0, 0);
+    }
+    return g;
+  };
+  // lane (query a = li, half lh) gets the 16 entries of its keys c = (r & 3) + 8 (r >> 2) + 4 lh: G^T[c - a + 31][a], through LDS
+  // diag: the upper form on the diagonal tile -- keep the lower entry where j <= i, 0 at j == i + 1
+  auto skew = [&](const f32x16& g0, const f32x16& g1, float (&term)[16], const bool diag) __attribute__((always_inline)) {
+    wave_lds_fence();   // the previous band's skewed reads are complete
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      gt[t * GLD + li] = g0[r];
+      gt[(32 + t) * GLD + li] = g1[r];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float v = gt[(c - li + 31) * GLD + li];
+      term[r] = !diag ? v : (c <= li ? term[r] : (c == li + 1 ? 0.f : v));
+    }
+  };
+  // first table row of the NEW tile (t >= 32) of the band of key chunk j0: lower form (j0 <= i0) rows N - 1 - i + j, upper form j - i - 2
+  auto new_tile_row = [&](const int j0, const bool upper) { return upper ? j0 - i0 - 1 : N + j0 - i0; };
+  PRE_T pre[NPRE];   // the table rows requested for the next band tile (registers: handed to the lambdas as an argument -- captured by
+                     // reference it stayed in scratch memory)
+  f32x16 ghi;   // the second tile of the last band of the running sequence = the first tile of the next band
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ghi[r] = 0.f;
+
   const int nchunks = (N + 31) / 32;
   for (int kc = 0; kc < nchunks; ++kc) {
+    const int j0 = kc * 32;
     __syncthreads();
     for (int i = tid; i < 32 * (DK / 4); i += 256) {
       const int r = i / (DK / 4), c = (i % (DK / 4)) * 4;
-      const int key = kc * 32 + r;
+      const int key = j0 + r;
       float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
       if (key < N) {
-        kv = *reinterpret_cast<const float4*>(kp + (long long)key * ld + c);
-        vv = *reinterpret_cast<const float4*>(vp + (long long)key * ld + c);
+        kv = *reinterpret_cast<const float4*>(kp + (key * ld + c));
+        vv = *reinterpret_cast<const float4*>(vp + (key * ld + c));
       }
       *reinterpret_cast<float4*>(Ks + r * LDS_LD + c) = kv;
       *reinterpret_cast<float4*>(Vs + r * LDS_LD + c) = vv;
     }
-    // shifted position term of this lane's 16 (query, key) pairs, requested before the MFMAs that hide its latency
+    // shifted position term of this lane's 16 (query, key) pairs (wave-uniform case split on j0 - i0; both are multiples of 32)
     float pterm[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float v = 0.f;
-      if (j < N && j != qi + 1) {
-        const int row = j <= qi ? qi : qi + 1;
-        const int col = j <= qi ? N - 1 - qi + j : j - qi - 2;
-        v = psb[(long long)row * ldp + col];
+    if (j0 <= i0) {         // lower form, P row N - 1 - i + j = (N - 1 + j0 - i0 - 31) + t  (every pair below the diagonal; at j0 == i0: j <= i)
+      if (kc == 0) {        // the sequence starts: both tiles
+        band_fetch(pre, new_tile_row(j0, false) - 32);
+        ghi = band_tile(pre, qx);
+        band_fetch(pre, new_tile_row(j0, false));
       }
-      pterm[r] = v;
+      const f32x16 g1 = band_tile(pre, qx);
+      if (j0 < i0) band_fetch(pre, new_tile_row(j0 + 32, false));   // the next chunk continues the lower sequence
+      skew(ghi, g1, pterm, false);
+      ghi = g1;
+    }
+    if (j0 >= i0) {         // upper form, P row j - i - 2 = (j0 - i0 - 33) + t  (j >= i + 2; j == i + 1 -> 0)
+      if (j0 == i0) {       // the sequence starts at the diagonal tile: the NEXT query's vector from here on, both tiles
+        load_qx(min(qi + 1, N - 1));
+        band_fetch(pre, new_tile_row(j0, true) - 32);
+        ghi = band_tile(pre, qx);
+        band_fetch(pre, new_tile_row(j0, true));
+      }
+      const f32x16 g1 = band_tile(pre, qx);
+      if (kc + 1 < nchunks) band_fetch(pre, new_tile_row(j0 + 32, true));
+      skew(ghi, g1, pterm, j0 == i0);
+      ghi = g1;
+      if (j0 == i0 + 32 && li == 31 && lh == 0) pterm[0] = 0.f;   // (a, c) = (31, 0): j == i + 1
     }
     __syncthreads();
 
-    f32x16 s;
+    f32x16 s;   // the content scores accumulate on top of the position term (one array instead of two)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int r = 0; r < 16; ++r) s[r] = pterm[r];
     const float* ka = Ks + li * LDS_LD + lh * 4;
 #pragma unroll
     for (int qq = 0; qq < QQ; ++qq) {
@@ -457,8 +576,8 @@ __global__ __launch_bounds__(256) void rel_attention_kernel(const float* __restr
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int key = kc * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float v = (s[r] + pterm[r]) / temperature;
+      const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = s[r] / temperature;
       v = key < N ? v : -INFINITY;
       s[r] = v;
       mx = fmaxf(mx, v);
@@ -489,7 +608,7 @@ __global__ __launch_bounds__(256) void rel_attention_kernel(const float* __restr
     }
   }
 
-  const int q = q0 + li;
+  const int q = i0 + li;
   if (q < N) {
     const float inv = 1.0f / l_run;
     float* orow = out + ((long long)b * N + q) * H + head * DK + 4 * lh;
@@ -596,8 +715,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(const float* _
       const int key = kc * 32 + r;
       float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
       if (key < N) {
-        kv = *reinterpret_cast<const float4*>(kp + (long long)key * ld + c4 * 4);
-        vv = *reinterpret_cast<const float4*>(vp + (long long)key * ld + c4 * 4);
+        kv = *reinterpret_cast<const float4*>(kp + (key * ld + c4 * 4));
+        vv = *reinterpret_cast<const float4*>(vp + (key * ld + c4 * 4));
       }
       // K row: [hi d 0 .. DK-1 | lo d 0 .. DK-1] as bf16
       const unsigned k0 = pk_bf16(kv.x, kv.y), k1 = pk_bf16(kv.z, kv.w);
@@ -706,6 +825,251 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_x3_kernel(const float* _
         v.z = valid ? o[d][4 * g + 2] * inv : 0.f;
         v.w = valid ? o[d][4 * g + 3] * inv : 0.f;
         *reinterpret_cast<float4*>(orow + d * 32 + 8 * g) = v;
+      }
+  }
+}
+
+// ---- Conformer relative-position attention in split precision (the decoder when its GEMMs run in bf16x3): rel_attention_kernel's
+// structure -- content scores, the position BAND of 64 table rows per (32-query, 32-key) tile, G^T = band . (q + v)^T, the skewed read --
+// on attention_x3_kernel's operands: every fp32 operand is hi + lo (two bf16) and a product keeps lo*hi + hi*lo + hi*hi on
+// v_mfma_f32_32x32x16_bf16.  The projected position table arrives pre-split from the packer (`att.pos.x3`: rows of DK bf16 hi | DK bf16
+// lo), so staging a band is a copy.  DK % 16 == 0; P . V runs on ceil(DK / 32) tiles (the rows past DK are never stored).
+template <int DK>
+__global__ __launch_bounds__(256, 2) void rel_attention_x3_kernel(const float* __restrict__ qkv, const unsigned* __restrict__ posx, int pos_rows,
+                                                                  const float* __restrict__ ub, const float* __restrict__ vb,
+                                                                  float* __restrict__ out, int N, int H, float temperature) {
+  static_assert(DK % 16 == 0, "head dim must be a multiple of 16");
+  constexpr int KS = DK + 4;            // words per K / band row: DK/2 (hi bf16) + DK/2 (lo bf16) + 4 pad
+  constexpr int VS = 36;                // words per Vt row: 16 (32 hi slots) + 16 (32 lo slots) + 4 pad
+  constexpr int DTP = (DK + 31) / 32;   // 32-wide tiles of the (padded) head dimension
+  constexpr int NS = DK / 16;           // k-steps over the head dimension
+  constexpr int GLD = 34;
+  constexpr int NB4 = 32 * (DK / 4);    // uint4 of one band tile (32 table rows)
+  constexpr int NPRE = (NB4 + 63) / 64; // ... per lane
+  __shared__ __attribute__((aligned(16))) unsigned Kh[32 * KS];
+  __shared__ __attribute__((aligned(16))) unsigned Vt[DTP * 32 * VS];
+  __shared__ __attribute__((aligned(16))) unsigned Pb[4][32 * KS];   // per wavefront: the 32 table rows of one band tile
+  __shared__ __attribute__((aligned(16))) float Gt[4][64 * GLD];     // per wavefront: G^T of the current band (two tiles)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int i0 = blockIdx.x * 128 + wave * 32;
+  const int ld = 3 * H;
+  const float* base = qkv + (long long)b * N * ld;
+  const float* qp = base + head * DK;
+  const float* kp = base + H + head * DK;
+  const float* vp = base + 2 * H + head * DK;
+  const unsigned* ph = posx + (long long)head * pos_rows * DK;   // this head's table: [pos_rows][DK words]
+  unsigned* const band = Pb[wave];
+  float* const gt = Gt[wave];
+
+  // query fragments: lane (query li, half lh) holds X[q][16 s + 8 lh .. + 7] for every k-step s, split once: q + u, and ONE set of
+  // position fragments -- q + v up to the diagonal, q_{i+1} + v from the diagonal tile's upper form on (rel_attention_kernel)
+  const int qi = min(i0 + li, N - 1);
+  bf16x8_t fh[NS], fl[NS], xh[NS], xl[NS];
+  auto load_frag = [&](const int row, const float* bias, bf16x8_t (&dh)[NS], bf16x8_t (&dl)[NS]) __attribute__((always_inline)) {
+    const float* qr = qp + (row * ld + lh * 8);
+    const float* br = bias + head * DK + lh * 8;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float4 a0 = *reinterpret_cast<const float4*>(qr + s * 16), a1 = *reinterpret_cast<const float4*>(qr + s * 16 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(br + s * 16), b1 = *reinterpret_cast<const float4*>(br + s * 16 + 4);
+      const float t8[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+      split8(t8, dh[s], dl[s]);
+    }
+  };
+  load_frag(qi, ub, fh, fl);
+  load_frag(qi, vb, xh, xl);
+
+  f32x16 o[DTP];
+#pragma unroll
+  for (int d = 0; d < DTP; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float inv_temp = 1.0f / temperature;
+
+  // the sliding band of rel_attention_kernel: one new tile of 32 (pre-split) table rows per key chunk, requested a chunk ahead
+  typedef u32x4v PRE_T;
+  auto band_fetch = [&](PRE_T (&pre)[NPRE], const int row_start) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = min(lane + 64 * i, NB4 - 1);
+      const int r = idx / (DK / 4), c4 = (idx % (DK / 4)) * 4;
+      const int row = min(max(row_start + r, 0), pos_rows - 1);
+      pre[i] = *reinterpret_cast<const u32x4v*>(ph + row * DK + c4);
+    }
+  };
+  auto band_tile = [&](const PRE_T (&pre)[NPRE]) __attribute__((always_inline)) -> f32x16 {
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < NB4) *reinterpret_cast<u32x4v*>(band + (idx / (DK / 4)) * KS + (idx % (DK / 4)) * 4) = pre[i];
+    }
+    wave_lds_fence();
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = 0.f;
+    const unsigned* pa = band + li * KS + lh * 4;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(pa + ks * 8));
+      const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(pa + DK / 2 + ks * 8));
+      g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[ks], g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[ks], g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[ks], g, 0, 0, 0);
+    }
+    return g;
+  };
+  auto skew = [&](const f32x16& g0, const f32x16& g1, float (&term)[16], const bool diag) __attribute__((always_inline)) {
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      gt[t * GLD + li] = g0[r];
+      gt[(32 + t) * GLD + li] = g1[r];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float v = gt[(c - li + 31) * GLD + li];
+      term[r] = !diag ? v : (c <= li ? term[r] : (c == li + 1 ? 0.f : v));
+    }
+  };
+  auto new_tile_row = [&](const int j0, const bool upper) { return upper ? j0 - i0 - 1 : N + j0 - i0; };
+  PRE_T pre[NPRE];
+  f32x16 ghi;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ghi[r] = 0.f;
+
+  const int nchunks = (N + 31) / 32;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int j0 = kc * 32;
+    __syncthreads();
+    for (int i = tid; i < 32 * (DK / 4); i += 256) {
+      const int r = i / (DK / 4), c4 = i % (DK / 4);
+      const int key = j0 + r;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (key < N) {
+        kv = *reinterpret_cast<const float4*>(kp + (key * ld + c4 * 4));
+        vv = *reinterpret_cast<const float4*>(vp + (key * ld + c4 * 4));
+      }
+      // K row: [hi d 0 .. DK-1 | lo d 0 .. DK-1] as bf16 (attention_x3_kernel's staging)
+      const unsigned k0 = pk_bf16(kv.x, kv.y), k1 = pk_bf16(kv.z, kv.w);
+      const float kx = __builtin_bit_cast(float, k0 << 16), ky = __builtin_bit_cast(float, k0 & 0xffff0000u);
+      const float kz = __builtin_bit_cast(float, k1 << 16), kw = __builtin_bit_cast(float, k1 & 0xffff0000u);
+      *reinterpret_cast<uint2*>(Kh + r * KS + c4 * 2) = make_uint2(k0, k1);
+      *reinterpret_cast<uint2*>(Kh + r * KS + DK / 2 + c4 * 2) = make_uint2(pk_bf16(kv.x - kx, kv.y - ky), pk_bf16(kv.z - kz, kv.w - kw));
+      // V transposed, key r -> slot (attention_x3_kernel); head-dim row d = 4 c4 + e at physical row (d & 3) (8 DTP) + (d >> 2): the
+      // padded rows DK .. 32 DTP - 1 get rows of their own, which nobody writes and whose products land in output rows nobody stores
+      const int rr = (r & 3) + 4 * (r >> 3), h = (r >> 2) & 1;
+      const int slot = 16 * (rr >> 3) + 8 * h + (rr & 7);
+      unsigned short* vt = reinterpret_cast<unsigned short*>(Vt) + c4 * (VS * 2) + slot;
+      const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 hb = (__bf16)vs[e];
+        const __bf16 lb = (__bf16)(vs[e] - (float)hb);
+        vt[e * (8 * DTP) * (VS * 2)] = __builtin_bit_cast(unsigned short, hb);
+        vt[e * (8 * DTP) * (VS * 2) + 32] = __builtin_bit_cast(unsigned short, lb);
+      }
+    }
+    float pterm[16];
+    if (j0 <= i0) {         // lower form (see rel_attention_kernel)
+      if (kc == 0) {
+        band_fetch(pre, new_tile_row(j0, false) - 32);
+        ghi = band_tile(pre);
+        band_fetch(pre, new_tile_row(j0, false));
+      }
+      const f32x16 g1 = band_tile(pre);
+      if (j0 < i0) band_fetch(pre, new_tile_row(j0 + 32, false));
+      skew(ghi, g1, pterm, false);
+      ghi = g1;
+    }
+    if (j0 >= i0) {         // upper form
+      if (j0 == i0) {
+        load_frag(min(qi + 1, N - 1), vb, xh, xl);
+        band_fetch(pre, new_tile_row(j0, true) - 32);
+        ghi = band_tile(pre);
+        band_fetch(pre, new_tile_row(j0, true));
+      }
+      const f32x16 g1 = band_tile(pre);
+      if (kc + 1 < nchunks) band_fetch(pre, new_tile_row(j0 + 32, true));
+      skew(ghi, g1, pterm, j0 == i0);
+      ghi = g1;
+      if (j0 == i0 + 32 && li == 31 && lh == 0) pterm[0] = 0.f;
+    }
+    __syncthreads();
+
+    f32x16 s;   // the content scores accumulate on top of the position term
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = pterm[r];
+    const unsigned* ka = Kh + li * KS + lh * 4;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ka + ks * 8));
+      const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ka + DK / 2 + ks * 8));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, fh[ks], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, fl[ks], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, fh[ks], s, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v = s[r] * inv_temp;
+      v = key < N ? v : -INFINITY;
+      s[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = __expf(m_run - m_new);
+    float psum = 0.f;
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pv[r] = __expf(s[r] - m_new);
+      psum += pv[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+    bf16x8_t pfh[2], pfl[2];
+    split8(pv, pfh[0], pfl[0]);
+    split8(pv + 8, pfh[1], pfl[1]);
+#pragma unroll
+    for (int d = 0; d < DTP; ++d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= corr;
+      const unsigned* va = Vt + ((li & 3) * (8 * DTP) + d * 8 + (li >> 2)) * VS + lh * 4;  // physical row of head-dim row d * 32 + li
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(va + s2 * 8));
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(va + 16 + s2 * 8));
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pfh[s2], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pfl[s2], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pfh[s2], o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  const int q = i0 + li;
+  if (q < N) {
+    const float inv = 1.0f / l_run;
+    float* orow = out + ((long long)b * N + q) * H + head * DK + 4 * lh;
+#pragma unroll
+    for (int d = 0; d < DTP; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (d * 32 + 8 * g + 4 * lh < DK) {
+          float4 v;
+          v.x = o[d][4 * g + 0] * inv; v.y = o[d][4 * g + 1] * inv; v.z = o[d][4 * g + 2] * inv; v.w = o[d][4 * g + 3] * inv;
+          *reinterpret_cast<float4*>(orow + d * 32 + 8 * g) = v;
+        }
       }
   }
 }
@@ -896,22 +1260,36 @@ __global__ __launch_bounds__(QT * 128, 2) void attention_x3_split_kernel(const f
 
 }  // namespace
 
-const char* launch_rel_attention(const float* qkv, const float* ps, int ldp, const float* u, float* out, int B, int N, int H, int n_head,
-                                 hipStream_t s) {
-  if (!qkv || !ps || !u || !out) return "rel_attention: null pointer";
-  if (B <= 0 || N <= 0 || n_head <= 0 || H % n_head || ldp < N) return "rel_attention: bad dims";
+const char* launch_rel_attention(const float* qkv, const float* pos, int pos_rows, const float* u, const float* v, float* out, int B, int N,
+                                 int H, int n_head, hipStream_t s, const float* pos_x3) {
+  if (!qkv || !pos || !u || !v || !out) return "rel_attention: null pointer";
+  if (B <= 0 || N <= 0 || n_head <= 0 || H % n_head || pos_rows < N) return "rel_attention: bad dims (the position table must cover N rows)";
   if (B > 65535 || n_head > 65535) return "rel_attention: batch / heads exceed the grid limit";
-  if (((uintptr_t)qkv | (uintptr_t)u | (uintptr_t)out) & 15) return "rel_attention: buffers must be 16-byte aligned";
+  if ((long long)N * 3 * H >= (1LL << 31) || (long long)pos_rows * (H / n_head) >= (1LL << 31)) return "rel_attention: one utterance must stay below 2^31 elements (32-bit offsets)";
+  if (((uintptr_t)qkv | (uintptr_t)pos | (uintptr_t)u | (uintptr_t)v | (uintptr_t)out) & 15) return "rel_attention: buffers must be 16-byte aligned";
   const int dk = H / n_head;
   const float temperature = sqrtf((float)H);  // sqrt(d_model), not sqrt(d_head) (conformer.py:384)
   dim3 grid((N + 127) / 128, n_head, B);
+  if (pos_x3) {  // split precision: the table pre-split by the packer
+    if ((uintptr_t)pos_x3 & 15) return "rel_attention: buffers must be 16-byte aligned";
+    const unsigned* px = reinterpret_cast<const unsigned*>(pos_x3);
+    switch (dk) {
+      case 16: hipLaunchKernelGGL(rel_attention_x3_kernel<16>, grid, dim3(256), 0, s, qkv, px, pos_rows, u, v, out, N, H, temperature); break;
+      case 32: hipLaunchKernelGGL(rel_attention_x3_kernel<32>, grid, dim3(256), 0, s, qkv, px, pos_rows, u, v, out, N, H, temperature); break;
+      case 48: hipLaunchKernelGGL(rel_attention_x3_kernel<48>, grid, dim3(256), 0, s, qkv, px, pos_rows, u, v, out, N, H, temperature); break;
+      case 64: hipLaunchKernelGGL(rel_attention_x3_kernel<64>, grid, dim3(256), 0, s, qkv, px, pos_rows, u, v, out, N, H, temperature); break;
+      case 96: hipLaunchKernelGGL(rel_attention_x3_kernel<96>, grid, dim3(256), 0, s, qkv, px, pos_rows, u, v, out, N, H, temperature); break;
+      default: return "rel_attention: the split-precision form needs a head dim of 16, 32, 48, 64 or 96";
+    }
+    return hipGetLastError() == hipSuccess ? nullptr : "rel_attention: launch failed";
+  }
   switch (dk) {
-    case 8: hipLaunchKernelGGL(rel_attention_kernel<8>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
-    case 16: hipLaunchKernelGGL(rel_attention_kernel<16>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
-    case 32: hipLaunchKernelGGL(rel_attention_kernel<32>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
-    case 48: hipLaunchKernelGGL(rel_attention_kernel<48>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
-    case 64: hipLaunchKernelGGL(rel_attention_kernel<64>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
-    case 96: hipLaunchKernelGGL(rel_attention_kernel<96>, grid, dim3(256), 0, s, qkv, ps, ldp, u, out, N, H, temperature); break;
+    case 8: hipLaunchKernelGGL(rel_attention_kernel<8>, grid, dim3(256), 0, s, qkv, pos, pos_rows, u, v, out, N, H, temperature); break;
+    case 16: hipLaunchKernelGGL(rel_attention_kernel<16>, grid, dim3(256), 0, s, qkv, pos, pos_rows, u, v, out, N, H, temperature); break;
+    case 32: hipLaunchKernelGGL(rel_attention_kernel<32>, grid, dim3(256), 0, s, qkv, pos, pos_rows, u, v, out, N, H, temperature); break;
+    case 48: hipLaunchKernelGGL(rel_attention_kernel<48>, grid, dim3(256), 0, s, qkv, pos, pos_rows, u, v, out, N, H, temperature); break;
+    case 64: hipLaunchKernelGGL(rel_attention_kernel<64>, grid, dim3(256), 0, s, qkv, pos, pos_rows, u, v, out, N, H, temperature); break;
+    case 96: hipLaunchKernelGGL(rel_attention_kernel<96>, grid, dim3(256), 0, s, qkv, pos, pos_rows, u, v, out, N, H, temperature); break;
     default: return "rel_attention: head dim must be one of 8, 16, 32, 48, 64, 96";
   }
   hipError_t err = hipGetLastError();

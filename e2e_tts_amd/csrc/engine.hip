@@ -42,9 +42,10 @@ struct CfGemm {
 struct CfLayer {
   const float *ff_lng[2], *ff_lnb[2];
   CfGemm ff_a[2], ff_b[2];  // FeedForwardModule x 2: Linear(H -> F), Linear(F -> H) (half-step factor folded in)
-  const float *att_lng, *att_lnb, *att_u;
+  const float *att_lng, *att_lnb, *att_u, *att_v;
   CfGemm att_qkv, att_o;
-  const float *pos[2], *posb[2];  // pos_proj(table) per head [n_head][rows][d_head] + v_bias . P bias [n_head][rows4]: stored / regenerated table
+  const float* pos[2];  // pos_proj(table) per head [n_head][rows][d_head]: stored / regenerated table
+  const float* posx[2] = {nullptr, nullptr};  // the same as bf16 hi | lo rows (decoder, optional): the split-precision attention kernel's operand
   uint64_t pos_rows[2];
   const float *cv_lng, *cv_lnb, *dw_w, *dw_b;
   CfGemm pw1, pw2;
@@ -110,7 +111,6 @@ struct e2etts_engine {
 
   // workspace
   DevBuf ids, lens64, lens32, spk, xa, xb, xs, xp, tmp, qkv, att, hid, p1, p2;
-  DevBuf relps;  // Conformer: unshifted position scores [B, n_head, N, ceil4(N)]
   DevBuf logd, durf, cum, mel64, mel32, posbuf, ppred, epred, pidx, eidx;
   DevBuf dx, dxb, mel, melpost, pn1, pn2;
   DevBuf melin, v0, v1, v2, v3, wav, pcm;
@@ -432,6 +432,7 @@ int bind_conformer(e2etts_engine* e, const char* side, int layers, std::vector<C
     RET(get_tensor(e, p + "att.ln.g", H, &f.att_lng));
     RET(get_tensor(e, p + "att.ln.b", H, &f.att_lnb));
     RET(get_tensor(e, p + "att.u", H, &f.att_u));
+    RET(get_tensor(e, p + "att.v", H, &f.att_v));
     RET(bind_cf_gemm(e, p + "att.wqkv", nullptr, 3 * H, H, f.att_qkv));  // LinearNorm default: no bias (U/blocks/utils.py:182)
     RET(bind_cf_gemm(e, p + "att.wo", nullptr, H, H, f.att_o));
     const uint64_t rows[2] = {(uint64_t)c.max_seq_len + 1, (uint64_t)c.pos_table_rows};
@@ -439,7 +440,8 @@ int bind_conformer(e2etts_engine* e, const char* side, int layers, std::vector<C
     for (int i = 0; i < 2; ++i) {
       f.pos_rows[i] = rows[i];
       RET(get_tensor(e, p + tag[i], nh * rows[i] * (H / nh), &f.pos[i]));
-      RET(get_tensor(e, p + tag[i] + "b", nh * ((rows[i] + 3) / 4 * 4), &f.posb[i]));
+      f.posx[i] = nullptr;
+      if (e->tensors.count(p + tag[i] + ".x3")) RET(get_tensor(e, p + tag[i] + ".x3", nh * rows[i] * (H / nh), &f.posx[i]));
     }
     RET(get_tensor(e, p + "cv.ln.g", H, &f.cv_lng));
     RET(get_tensor(e, p + "cv.ln.b", H, &f.cv_lnb));
@@ -669,13 +671,10 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
 int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3) {
   const auto& c = e->cfg;
   const int H = c.hidden, F = c.ffn_dim, nh = c.n_head, dh = H / nh;
-  const int ldp = (N + 3) / 4 * 4;
-  RET(ensure(e, e->relps, (size_t)B * nh * N * ldp * 4));
   float* qkv = ptr<float>(e->qkv);
   float* att = ptr<float>(e->att);
   float* tmp = ptr<float>(e->tmp);
   float* hid = ptr<float>(e->hid);
-  float* relps = ptr<float>(e->relps);
   float *cur = x, *oth = xalt;
   const int tsel = N > c.max_seq_len ? 1 : 0;  // eval-time regenerated table (:339-344)
   auto gemm = [&](const CfGemm& g, const float* in, float* out, int cin, int cout, const float* res, int act = ACT_NONE) -> int {
@@ -691,25 +690,19 @@ int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, float*
     return E2ETTS_OK;
   };
   for (const CfLayer& f : layers) {
-    if ((uint64_t)ldp > f.pos_rows[tsel])
+    if ((uint64_t)N > f.pos_rows[tsel])
       return e->fail(E2ETTS_EINVAL, "sequence of %d rows exceeds the Conformer position table (%llu rows)", N, (unsigned long long)f.pos_rows[tsel]);
     for (int half = 0; half < 2; ++half) {
       if (half == 1) {
         // MultiHeadedSelfAttentionModule (:335-353) + RelativeMultiHeadAttention (:399-440)
         RET(ln(cur, tmp, f.att_lng, f.att_lnb, nullptr));
         RET(gemm(f.att_qkv, tmp, qkv, H, 3 * H, nullptr));
-        for (int h = 0; h < nh; ++h) {  // position scores (q + v_bias) . P^T of head h for the whole batch: q . P_h^T + (v_h . P_h)
-          ConvParams p;
-          p.B = B; p.T = N; p.in = qkv + h * dh; p.in_ld = 3 * H; p.in_bs = (long long)N * 3 * H; p.Cin = dh;
-          p.w = f.pos[tsel] + (size_t)h * f.pos_rows[tsel] * dh;
-          p.bias = f.posb[tsel] + (size_t)h * ((f.pos_rows[tsel] + 3) / 4 * 4);
-          p.Cout = ldp; p.out = relps + (size_t)h * N * ldp; p.out_ld = ldp; p.out_bs = (long long)nh * N * ldp;
-          RET(conv(e, p));
-        }
-        {
-          const double fl = 4.0 * B * nh * (double)N * N * dh;
-          ProfScope ps(e, "rel_attention", fl, 4.0 * B * ((double)nh * N * ldp + 4.0 * N * H));
-          KCHK(e, launch_rel_attention(qkv, relps, ldp, f.att_u, att, B, N, H, nh, e->stream));
+        {  // the shifted position scores are computed inside the kernel, from this layer's projected table (attention.hip)
+          // FLOPs: content scores and P . V (4 N^2 d_h per head) + the position bands (2 x 32 x 64 x d_h per 32 x 32 tile = 4 N^2 d_h)
+          const double fl = 8.0 * B * nh * (double)N * N * dh;
+          ProfScope ps(e, "rel_attention", fl, 4.0 * B * (4.0 * N * H) + 4.0 * nh * N * dh);
+          KCHK(e, launch_rel_attention(qkv, f.pos[tsel], (int)f.pos_rows[tsel], f.att_u, f.att_v, att, B, N, H, nh, e->stream,
+                                       x3 ? f.posx[tsel] : nullptr));
         }
         RET(gemm(f.att_o, att, oth, H, H, cur));
         std::swap(cur, oth);

@@ -182,11 +182,13 @@ const char* launch_glu(const float* in, float* out, long long rows, int C, hipSt
 // depthwise conv (k taps, zero "same" padding over [0, N), w [k][C], BatchNorm folded into w / bias) + Swish; channels-last
 const char* launch_dwconv_swish(const float* in, const float* w, const float* bias, float* out, int B, int N, int C, int k, hipStream_t s);
 // Relative-position self-attention of RelativeMultiHeadAttention (conformer.py:399-440): no key mask (nn.Sequential passes no mask,
-// :252), score = ((q + u) . k + shift((q + v) . P)) / sqrt(H).  qkv [B, N, 3H] as in launch_attention; u [H] (heads flattened);
-// ps [B, n_head, N, ldp]: the UNSHIFTED position scores (q + v) . P[c], c < N, which _relative_shift (:432-440) re-indexes:
-// (i, j <= i) -> ps[i][N - 1 - i + j]; (i, i + 1) -> 0; (i, j > i + 1) -> ps[i + 1][j - i - 2].  out [B, N, H].
-const char* launch_rel_attention(const float* qkv, const float* ps, int ldp, const float* u, float* out, int B, int N, int H, int n_head,
-                                 hipStream_t s);
+// :252), score = ((q + u) . k + shift((q + v) . P)) / sqrt(H), where _relative_shift (:432-440) re-indexes the position scores as
+// (i, j <= i) -> (q_i + v) . P[N - 1 - i + j]; (i, i + 1) -> 0; (i, j > i + 1) -> (q_{i+1} + v) . P[j - i - 2].  The kernel computes those
+// entries itself from the projected position table (no [B, heads, N, N] tensor).  qkv [B, N, 3H] as in launch_attention; u, v [H] (heads
+// flattened); pos [n_head][pos_rows][H / n_head] = pos_proj(table) per head (pos_rows >= N); out [B, N, H].
+// pos_x3 (optional): the same table as bf16 hi | lo halves per row (packer: `att.pos.x3`) -> the split-precision kernel (decoder, bf16x3 mode).
+const char* launch_rel_attention(const float* qkv, const float* pos, int pos_rows, const float* u, const float* v, float* out, int B, int N,
+                                 int H, int n_head, hipStream_t s, const float* pos_x3 = nullptr);
 
 // tempo change without pitch change (WSOLA; small_kernels.hip): x int16 [n_in] -> out int16 [n_out <= n_frames * n / 2 + n / 2]
 const char* launch_wsola(const int16_t* x, long long n_in, int16_t* out, long long n_out, double speed, int n, int delta, int n_frames,

@@ -95,6 +95,18 @@ def pack_x3(w2: np.ndarray, KW: int, Cin: int) -> np.ndarray:
     return np.ascontiguousarray(out).reshape(cout, -1).view(np.float32)
 
 
+def split_rows_x3(x: np.ndarray) -> np.ndarray:
+    """fp32 [..., D] -> split-precision rows [..., D] of 32-bit words: D bf16 hi (= bf16(x), round to nearest even) followed by D bf16 lo
+    (= bf16(x - hi)); the operand format of the bf16x3 attention kernels (D even)."""
+    def bf16_bits(v):
+        u = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32)
+        return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    hi = bf16_bits(x)
+    lo = bf16_bits(x - (hi.astype(np.uint32) << np.uint32(16)).view(np.float32))
+    return np.ascontiguousarray(np.concatenate([hi, lo], axis=-1)).view(np.float32)
+
+
 def polyphase_upsampler(w: np.ndarray, b: np.ndarray, stride: int):
     """ConvTranspose1d weight [Cin, Cout, K = 2s] (pad s/2) -> 3-tap conv weight [s*Cout, 3*Cin], bias [s*Cout].
 
@@ -141,8 +153,8 @@ def _pack_conformer(dims: EngineDims, A, out) -> None:
 
     Folded here: the half-step factor into the second FFN Linear (x 0.5 is exact); BatchNorm (eval) into the depthwise conv;
     pos_proj(position table) per layer -- it does not depend on the input -- laid out per head [n_head][rows][d_head], once from
-    the stored table (`att.pos`, N <= max_seq_len) and once from the regenerated one (`att.posr`, conformer.py:339-344); and
-    v_bias . P[c] as the bias vector of the position-score GEMM (`att.posb`, rows padded to a multiple of 4 per head)."""
+    the stored table (`att.pos`, N <= max_seq_len) and once from the regenerated one (`att.posr`, conformer.py:339-344).  u_bias and
+    v_bias travel as they are (`att.u`, `att.v`, heads flattened): the attention kernel adds them to its query fragments."""
     H, F, nh, k = dims.hidden, dims.ffn_dim, dims.n_head, dims.ffn_k1
     dh = H // nh
     need = _need
@@ -168,16 +180,15 @@ def _pack_conformer(dims: EngineDims, A, out) -> None:
                 [need(A, f"{a}.attention.{w}.linear.weight", (H, H)) for w in ("query_proj", "key_proj", "value_proj")], 0)
             out[q + "att.wo"] = need(A, f"{a}.attention.out_proj.linear.weight", (H, H))
             out[q + "att.u"] = need(A, f"{a}.attention.u_bias", (nh, dh)).reshape(H)
+            out[q + "att.v"] = need(A, f"{a}.attention.v_bias", (nh, dh)).reshape(H)
             wp = need(A, f"{a}.attention.pos_proj.linear.weight", (H, H))
-            vb = need(A, f"{a}.attention.v_bias", (nh, dh))
             stored = need(A, f"{a}.positional_encoding", (1, dims.max_seq_len + 1, H))[0]
             for tag, table in (("pos", stored), ("posr", regen)):
                 rows = table.shape[0]
                 ph = np.ascontiguousarray((table @ wp.T).astype(np.float32).reshape(rows, nh, dh).transpose(1, 0, 2))
-                pb = np.zeros((nh, (rows + 3) // 4 * 4), np.float32)
-                pb[:, :rows] = np.einsum("hrd,hd->hr", ph, vb)
                 out[q + f"att.{tag}"] = ph
-                out[q + f"att.{tag}b"] = pb
+                if short == "dec" and dh % 16 == 0:  # split-precision image for rel_attention_x3_kernel: rows of dh bf16 hi | dh bf16 lo
+                    out[q + f"att.{tag}.x3"] = split_rows_x3(ph)
             m = f"{s}.2.module.sequential"
             out[q + "cv.ln.g"] = need(A, f"{m}.0.weight", (H,))
             out[q + "cv.ln.b"] = need(A, f"{m}.0.bias", (H,))

@@ -395,14 +395,12 @@ __global__ __launch_bounds__(256, 2) void rel_attention_kernel(const float* __re
   constexpr int DT = (DK + 31) / 32;
   constexpr int LDS_LD = DT * 32 + 4;
   constexpr int QQ = DK / 8;
-  constexpr int PLD = DK + 4;           // band row stride (floats): (DK + 4) / 4 is odd -> a ds_read_b128 of 16 rows covers the 64 banks once
-  constexpr int GLD = 34;               // G^T row stride: the skewed read (row c - a + 31, column a) then walks distinct banks
-  constexpr int NB4 = 32 * (DK / 4);    // float4 of one band tile (32 table rows)
-  constexpr int NPRE = (NB4 + 63) / 64; // ... per lane
+  constexpr int GLD = 68;               // G row stride (query-major [a][t], 64 + 4): float4 writes of 16 rows cover the 64 banks once, and
+                                        // the skewed read (row a, column c - a + 31) walks 3 a + const: distinct banks
+  constexpr int NPRE = QQ;              // float4 fragments of one band tile per lane
   __shared__ __attribute__((aligned(16))) float Ks[32 * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Vs[32 * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Pb[4][32 * PLD];   // per wavefront: the 32 table rows of one band tile
-  __shared__ __attribute__((aligned(16))) float Gt[4][64 * GLD];   // per wavefront: G^T of the current band (two tiles)
+  __shared__ __attribute__((aligned(16))) float Gt[4][32 * GLD];   // per wavefront: G of the current band, [query a][t 0..63]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -414,7 +412,6 @@ __global__ __launch_bounds__(256, 2) void rel_attention_kernel(const float* __re
   const float* kp = base + H + head * DK;
   const float* vp = base + 2 * H + head * DK;
   const float* ph = pos + (long long)head * pos_rows * DK;   // this head's projected position table [pos_rows][DK]
-  float* const band = Pb[wave];
   float* const gt = Gt[wave];
 
   const int qi = min(i0 + li, N - 1);  // this lane's query (clamped: rows >= N are computed and dropped)
@@ -456,58 +453,50 @@ __global__ __launch_bounds__(256, 2) void rel_attention_kernel(const float* __re
   float m_run = -INFINITY, l_run = 0.f;
 
   // The band SLIDES: the next key chunk's band is this one's shifted by 32 table rows, so its first G^T tile (t < 32) is this chunk's
-  // second one (t >= 32) -- P[row] . x does not depend on the chunk.  Per chunk ONE new tile of 32 table rows is staged and multiplied
-  // (both tiles only where a sequence starts: the first chunk, and the upper form at the diagonal), and its rows are requested one
-  // chunk ahead (`pre`), so their trip through L2 sits behind the previous chunk's arithmetic.
-  typedef f32x4v PRE_T;   // a native vector (float4 / uint4 are structs of unions: an array of them carried around the chunk loop stayed in scratch memory)
+  // second one (t >= 32) -- P[row] . x does not depend on the chunk.  Per chunk ONE new tile of 32 table rows is multiplied (both tiles
+  // only where a sequence starts: the first chunk, and the upper form at the diagonal).  The table rows are the A operand of that
+  // product, and each lane fetches exactly ITS fragments -- row li of the tile, channels 8 qq + 4 lh .. + 3 -- straight from the table
+  // (L2-resident: N x DK floats per head) into registers, one chunk ahead (`pre`): no LDS staging, and the trip through L2 sits behind
+  // the previous chunk's arithmetic.
+  typedef f32x4v PRE_T;   // a native vector (float4 is a struct of unions: an array of them carried around the chunk loop stayed in scratch memory)
   auto band_fetch = [&](PRE_T (&pre)[NPRE], const int row_start) __attribute__((always_inline)) {
+    const int row = min(max(row_start + li, 0), pos_rows - 1);   // rows outside [0, N) feed entries nobody selects
+    const float* pr = ph + (row * DK + lh * 4);
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int idx = min(lane + 64 * i, NB4 - 1);
-      const int r = idx / (DK / 4), c4 = (idx % (DK / 4)) * 4;
-      const int row = min(max(row_start + r, 0), pos_rows - 1);   // rows outside [0, N) feed entries nobody selects
-      pre[i] = *reinterpret_cast<const f32x4v*>(ph + row * DK + c4);
-    }
+    for (int qq = 0; qq < QQ; ++qq) pre[qq] = *reinterpret_cast<const f32x4v*>(pr + qq * 8);
   };
   // G^T tile of the 32 table rows in `pre`: [t][a] = P[row_start + t] . x_a (32 x 32, the orientation of S^T = K . Q^T)
   auto band_tile = [&](const PRE_T (&pre)[NPRE], const float4 (&x)[QQ]) __attribute__((always_inline)) -> f32x16 {
-    wave_lds_fence();   // the previous tile's fragment reads are complete in every lane
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < NB4) *reinterpret_cast<f32x4v*>(band + (idx / (DK / 4)) * PLD + (idx % (DK / 4)) * 4) = pre[i];
-    }
-    wave_lds_fence();
     f32x16 g;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = 0.f;
-    const float* pa = band + li * PLD + lh * 4;
 #pragma unroll
     for (int qq = 0; qq < QQ; ++qq) {
-      const float4 a = *reinterpret_cast<const float4*>(pa + qq * 8);
-      g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, x[qq].x, g, 0, 0, 0);
-      g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, x[qq].y, g, 0, 0, 0);
-      g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, x[qq].z, g, 0, 0, 0);
-      g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, x[qq].w, g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_32x32x2f32(pre[qq].x, x[qq].x, g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_32x32x2f32(pre[qq].y, x[qq].y, g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_32x32x2f32(pre[qq].z, x[qq].z, g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_32x32x2f32(pre[qq].w, x[qq].w, g, 0, 0, 0);
     }
     return g;
   };
-  // lane (query a = li, half lh) gets the 16 entries of its keys c = (r & 3) + 8 (r >> 2) + 4 lh: G^T[c - a + 31][a], through LDS
+  // lane (query a = li, half lh) gets the 16 entries of its keys c = (r & 3) + 8 (r >> 2) + 4 lh: G[a][c - a + 31], through LDS.  A lane
+  // holds G^T[t][a] for t = (r & 3) + 8 (r >> 2) + 4 lh: four consecutive t per register quad -> one float4 write into row a.
   // diag: the upper form on the diagonal tile -- keep the lower entry where j <= i, 0 at j == i + 1
   auto skew = [&](const f32x16& g0, const f32x16& g1, float (&term)[16], const bool diag) __attribute__((always_inline)) {
     wave_lds_fence();   // the previous band's skewed reads are complete
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      gt[t * GLD + li] = g0[r];
-      gt[(32 + t) * GLD + li] = g1[r];
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int t = 8 * q4 + 4 * lh;
+      *reinterpret_cast<float4*>(gt + li * GLD + t) = make_float4(g0[4 * q4], g0[4 * q4 + 1], g0[4 * q4 + 2], g0[4 * q4 + 3]);
+      *reinterpret_cast<float4*>(gt + li * GLD + 32 + t) = make_float4(g1[4 * q4], g1[4 * q4 + 1], g1[4 * q4 + 2], g1[4 * q4 + 3]);
     }
     wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float v = gt[(c - li + 31) * GLD + li];
-      term[r] = !diag ? v : (c <= li ? term[r] : (c == li + 1 ? 0.f : v));
+      const float v = gt[li * GLD + (c - li + 31)];
+      const bool keep = diag && c <= li, zero = diag && c == li + 1;
+      term[r] = keep ? term[r] : (zero ? 0.f : v);
     }
   };
   // first table row of the NEW tile (t >= 32) of the band of key chunk j0: lower form (j0 <= i0) rows N - 1 - i + j, upper form j - i - 2
@@ -843,13 +832,11 @@ __global__ __launch_bounds__(256, 2) void rel_attention_x3_kernel(const float* _
   constexpr int VS = 36;                // words per Vt row: 16 (32 hi slots) + 16 (32 lo slots) + 4 pad
   constexpr int DTP = (DK + 31) / 32;   // 32-wide tiles of the (padded) head dimension
   constexpr int NS = DK / 16;           // k-steps over the head dimension
-  constexpr int GLD = 34;
-  constexpr int NB4 = 32 * (DK / 4);    // uint4 of one band tile (32 table rows)
-  constexpr int NPRE = (NB4 + 63) / 64; // ... per lane
+  constexpr int GLD = 68;               // rel_attention_kernel's exchange layout: [query a][t 0..63], 64 + 4
+  constexpr int NPRE = 2 * NS;          // uint4 fragments of one band tile per lane: hi and lo of every k-step
   __shared__ __attribute__((aligned(16))) unsigned Kh[32 * KS];
   __shared__ __attribute__((aligned(16))) unsigned Vt[DTP * 32 * VS];
-  __shared__ __attribute__((aligned(16))) unsigned Pb[4][32 * KS];   // per wavefront: the 32 table rows of one band tile
-  __shared__ __attribute__((aligned(16))) float Gt[4][64 * GLD];     // per wavefront: G^T of the current band (two tiles)
+  __shared__ __attribute__((aligned(16))) float Gt[4][32 * GLD];     // per wavefront: G of the current band
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -861,7 +848,6 @@ __global__ __launch_bounds__(256, 2) void rel_attention_x3_kernel(const float* _
   const float* kp = base + H + head * DK;
   const float* vp = base + 2 * H + head * DK;
   const unsigned* ph = posx + (long long)head * pos_rows * DK;   // this head's table: [pos_rows][DK words]
-  unsigned* const band = Pb[wave];
   float* const gt = Gt[wave];
 
   // query fragments: lane (query li, half lh) holds X[q][16 s + 8 lh .. + 7] for every k-step s, split once: q + u, and ONE set of
@@ -890,33 +876,26 @@ __global__ __launch_bounds__(256, 2) void rel_attention_x3_kernel(const float* _
   float m_run = -INFINITY, l_run = 0.f;
   const float inv_temp = 1.0f / temperature;
 
-  // the sliding band of rel_attention_kernel: one new tile of 32 (pre-split) table rows per key chunk, requested a chunk ahead
+  // the sliding band of rel_attention_kernel: one new tile of 32 (pre-split) table rows per key chunk, each lane fetching its own A
+  // fragments (row li: bf16 hi d = 16 ks + 8 lh .. + 7 and the matching lo) from the table into registers a chunk ahead
   typedef u32x4v PRE_T;
   auto band_fetch = [&](PRE_T (&pre)[NPRE], const int row_start) __attribute__((always_inline)) {
+    const int row = min(max(row_start + li, 0), pos_rows - 1);
+    const unsigned* pr = ph + (row * DK + lh * 4);
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int idx = min(lane + 64 * i, NB4 - 1);
-      const int r = idx / (DK / 4), c4 = (idx % (DK / 4)) * 4;
-      const int row = min(max(row_start + r, 0), pos_rows - 1);
-      pre[i] = *reinterpret_cast<const u32x4v*>(ph + row * DK + c4);
+    for (int ks = 0; ks < NS; ++ks) {
+      pre[2 * ks] = *reinterpret_cast<const u32x4v*>(pr + ks * 8);
+      pre[2 * ks + 1] = *reinterpret_cast<const u32x4v*>(pr + DK / 2 + ks * 8);
     }
   };
   auto band_tile = [&](const PRE_T (&pre)[NPRE]) __attribute__((always_inline)) -> f32x16 {
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int idx = lane + 64 * i;
-      if (idx < NB4) *reinterpret_cast<u32x4v*>(band + (idx / (DK / 4)) * KS + (idx % (DK / 4)) * 4) = pre[i];
-    }
-    wave_lds_fence();
     f32x16 g;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = 0.f;
-    const unsigned* pa = band + li * KS + lh * 4;
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) {
-      const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(pa + ks * 8));
-      const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(pa + DK / 2 + ks * 8));
+      const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, pre[2 * ks]);
+      const bf16x8_t al = __builtin_bit_cast(bf16x8_t, pre[2 * ks + 1]);
       g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[ks], g, 0, 0, 0);
       g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[ks], g, 0, 0, 0);
       g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[ks], g, 0, 0, 0);
@@ -926,17 +905,18 @@ __global__ __launch_bounds__(256, 2) void rel_attention_x3_kernel(const float* _
   auto skew = [&](const f32x16& g0, const f32x16& g1, float (&term)[16], const bool diag) __attribute__((always_inline)) {
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      gt[t * GLD + li] = g0[r];
-      gt[(32 + t) * GLD + li] = g1[r];
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int t = 8 * q4 + 4 * lh;
+      *reinterpret_cast<float4*>(gt + li * GLD + t) = make_float4(g0[4 * q4], g0[4 * q4 + 1], g0[4 * q4 + 2], g0[4 * q4 + 3]);
+      *reinterpret_cast<float4*>(gt + li * GLD + 32 + t) = make_float4(g1[4 * q4], g1[4 * q4 + 1], g1[4 * q4 + 2], g1[4 * q4 + 3]);
     }
     wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float v = gt[(c - li + 31) * GLD + li];
-      term[r] = !diag ? v : (c <= li ? term[r] : (c == li + 1 ? 0.f : v));
+      const float v = gt[li * GLD + (c - li + 31)];
+      const bool keep = diag && c <= li, zero = diag && c == li + 1;
+      term[r] = keep ? term[r] : (zero ? 0.f : v);
     }
   };
   auto new_tile_row = [&](const int j0, const bool upper) { return upper ? j0 - i0 - 1 : N + j0 - i0; };
@@ -1318,8 +1298,10 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
     rm.n = 0;
     if (!lens || !lens_host || B > ROWMAP_MAX) return padded;
     rm.n = B;
+    rm.identity();   // slots ordered by length, longest first (stable): a unit's cost grows with its utterance's length
+    std::stable_sort(rm.idx, rm.idx + B, [&](unsigned char x, unsigned char y) { return lens_host[x] > lens_host[y]; });
     rm.cum[0] = 0;
-    for (int b = 0; b < B; ++b) rm.cum[b + 1] = rm.cum[b] + (std::min(std::max(lens_host[b], 0), N) + qrows - 1) / qrows * n_head;
+    for (int k = 0; k < B; ++k) rm.cum[k + 1] = rm.cum[k] + (std::min(std::max(lens_host[rm.idx[k]], 0), N) + qrows - 1) / qrows * n_head;
     return dim3((unsigned)std::max(rm.cum[B], 1));
   };
   const bool split = (dk == 64 || dk == 128 || dk == 192) && (long long)gs.x * gs.y * gs.z <= split_max;

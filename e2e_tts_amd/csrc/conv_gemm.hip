@@ -650,6 +650,7 @@ const char* launch_cfg_impl(const ConvParams& p, hipStream_t s) {
   long long groups = (long long)gx * p.B;
   if (compact) {  // row groups per utterance from ITS rows; the kernel re-derives the same counts from act_rows[b] on the device
     rm.n = p.B;
+    rm.identity();
     rm.cum[0] = 0;
     for (int b = 0; b < p.B; ++b) {
       const int mt = (std::min(std::max(p.act_rows_host[b], 0), p.T) + BM - 1) / BM;

@@ -317,6 +317,7 @@ static long long ragged_units(const ConvParams& p, int rows, int padded_per_utt,
   rm.n = 0;
   if (!(p.act_rows && p.act_rows_host && p.B <= ROWMAP_MAX)) return (long long)padded_per_utt * p.B;
   rm.n = p.B;
+  rm.identity();
   rm.cum[0] = 0;
   for (int b = 0; b < p.B; ++b) rm.cum[b + 1] = rm.cum[b] + (std::min(std::max(p.act_rows_host[b], 0), p.T) + rows - 1) / rows;
   return rm.cum[p.B];

@@ -709,13 +709,9 @@ int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, float*
         // ConformerConvModule (:468-481): LayerNorm, pointwise 2H + GLU, depthwise k + BatchNorm + Swish, pointwise
         RET(ln(cur, tmp, f.cv_lng, f.cv_lnb, nullptr));
         RET(gemm(f.pw1, tmp, hid, H, 2 * H, nullptr));
-        {
-          ProfScope ps(e, "misc", 0, 12.0 * B * N * H);
-          KCHK(e, launch_glu(hid, att, (long long)B * N, H, e->stream));
-        }
-        {
-          ProfScope ps(e, "dwconv_swish", 2.0 * B * N * (double)H * c.ffn_k1, 8.0 * B * N * H);
-          KCHK(e, launch_dwconv_swish(att, f.dw_w, f.dw_b, tmp, B, N, H, c.ffn_k1, e->stream));
+        {  // GLU + depthwise k + BatchNorm + Swish in one pass (small_kernels.hip); `att` is scratch for shapes without a fused form
+          ProfScope ps(e, "dwconv_glu_swish", 2.0 * B * N * (double)H * c.ffn_k1, 12.0 * B * N * H);
+          KCHK(e, launch_dwconv_glu_swish(hid, f.dw_w, f.dw_b, tmp, att, B, N, H, c.ffn_k1, e->stream));
         }
         RET(gemm(f.pw2, tmp, oth, H, H, cur));
         std::swap(cur, oth);

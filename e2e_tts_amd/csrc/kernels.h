@@ -18,14 +18,18 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_SWISH = 
 constexpr int ROWMAP_MAX = 64;  // utterances per launch the table holds; larger ragged batches keep the padded grid
 struct RowMap {
   int n = 0;                  // 0: uniform grid (every utterance has the same number of units)
-  int cum[ROWMAP_MAX + 1];    // cum[b] = units of utterances < b; cum[n] = all units
+  int cum[ROWMAP_MAX + 1];    // cum[k] = units of the slots < k; cum[n] = all units
+  unsigned char idx[ROWMAP_MAX];  // slot k holds utterance idx[k].  Identity for the convolutions (their units cost the same wherever they
+                              // lie); the attention launcher orders the slots by length, longest first: its units cost ~ the utterance's
+                              // length, and with the long ones dispatched first the short ones fill the tail of the launch
+  void identity() { for (int i = 0; i < ROWMAP_MAX; ++i) idx[i] = (unsigned char)i; }
 };
 // (b, local unit) of unit g; false when g lies beyond the last unit (the grid is padded to a multiple of 8)
 __device__ __forceinline__ bool rowmap_find(const RowMap& rm, int g, int& b, int& local) {
   if (g >= rm.cum[rm.n]) return false;
   int k = 0;
   for (int i = 1; i < rm.n; ++i) k += g >= rm.cum[i] ? 1 : 0;
-  b = k;
+  b = rm.idx[k];
   local = g - rm.cum[k];
   return true;
 }
@@ -181,6 +185,10 @@ const char* launch_istft(const float* q, int ldq, float* specphase, float* ri, f
 const char* launch_glu(const float* in, float* out, long long rows, int C, hipStream_t s);          // [rows, 2C] -> [rows, C]
 // depthwise conv (k taps, zero "same" padding over [0, N), w [k][C], BatchNorm folded into w / bias) + Swish; channels-last
 const char* launch_dwconv_swish(const float* in, const float* w, const float* bias, float* out, int B, int N, int C, int k, hipStream_t s);
+// The two above in one pass: out = Swish(BN(dwconv_k(GLU(in)))), in [B, N, 2C] -> out [B, N, C]; same bits as the two-kernel form, which
+// it falls back to (through `scratch`, [B, N, C]) for kernel sizes / channel counts without a fused instantiation
+const char* launch_dwconv_glu_swish(const float* in, const float* w, const float* bias, float* out, float* scratch, int B, int N, int C, int k,
+                                    hipStream_t s, bool* fused_out = nullptr);
 // Relative-position self-attention of RelativeMultiHeadAttention (conformer.py:399-440): no key mask (nn.Sequential passes no mask,
 // :252), score = ((q + u) . k + shift((q + v) . P)) / sqrt(H), where _relative_shift (:432-440) re-indexes the position scores as
 // (i, j <= i) -> (q_i + v) . P[N - 1 - i + j]; (i, i + 1) -> 0; (i, j > i + 1) -> (q_{i+1} + v) . P[j - i - 2].  The kernel computes those

@@ -340,6 +340,7 @@ const char* launch_chain_cfg(const ChainParams& p, hipStream_t s) {
   RowMap rm;
   if (p.act_rows && p.act_rows_host && p.B <= ROWMAP_MAX) {  // ragged: only the blocks of tiles that exist (resblock_pair.hip)
     rm.n = p.B;
+    rm.identity();
     rm.cum[0] = 0;
     for (int b = 0; b < p.B; ++b) {
       const int mt = (std::min(std::max(p.act_rows_host[b], 0), p.T) + RO - 1) / RO;

@@ -419,6 +419,7 @@ const char* launch_pair_cfg(const PairParams& p, hipStream_t s) {
   RowMap rm;
   if (p.act_rows && p.act_rows_host && p.B <= ROWMAP_MAX) {  // ragged: only the blocks of tiles that exist (at most 7 spare per utterance)
     rm.n = p.B;
+    rm.identity();
     rm.cum[0] = 0;
     for (int b = 0; b < p.B; ++b) {
       const int mt = (std::min(std::max(p.act_rows_host[b], 0), p.T) + BMO - 1) / BMO;

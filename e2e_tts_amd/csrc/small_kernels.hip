@@ -460,6 +460,65 @@ __global__ void dwconv_swish_kernel(const float4* __restrict__ in, const float4*
   out[(long long)b * N * c4 + i] = v;
 }
 
+// GLU -> depthwise Conv1d(K) -> BatchNorm (folded) -> Swish in ONE pass over the pointwise convolution's 2 C output channels (round 3; the
+// two kernels above cost 21 + 54 us per layer at B = 32, T = 768, against ~20 us of HBM time for what they move).  A workgroup owns a
+// tile of 64 frames x CT channels: the GLU of the tile's rows and of (K - 1) / 2 halo rows either side goes to LDS once (every input
+// element's sigmoid computed once, not K times); a thread then owns 4 channels of FPT consecutive frames, holds its K weight float4s in
+// registers, and streams the FPT + K - 1 rows it needs past its FPT accumulators -- one LDS read per row, the products added in tap
+// order as dwconv_swish_kernel adds them (rows outside [0, N) are zeros: fma(0, w, acc) = acc), so the two forms give the same bits.
+template <int K, int CT>
+__global__ __launch_bounds__(256) void dwconv_glu_swish_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out, int N, int C) {
+  constexpr int FR = 64, NC4 = CT / 4, NFG = 256 / NC4, FPT = FR / NFG, HALF = (K - 1) / 2, ROWS = FR + K - 1, LD = CT + 4;
+  static_assert(256 % NC4 == 0 && FR % NFG == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) float dw_xs[];   // [ROWS][LD]
+  const int tid = threadIdx.x, c4 = tid % NC4, fg = tid / NC4;
+  const int b = blockIdx.z, c0 = blockIdx.y * CT, t0 = blockIdx.x * FR;
+  const float* inb = in + (long long)b * N * 2 * C;
+  for (int i = tid; i < ROWS * NC4; i += 256) {
+    const int r = i / NC4, cc = i % NC4;
+    const int t = t0 - HALF + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < N) {
+      const float4 a = *reinterpret_cast<const float4*>(inb + (long long)t * 2 * C + c0 + cc * 4);
+      const float4 g = *reinterpret_cast<const float4*>(inb + (long long)t * 2 * C + C + c0 + cc * 4);
+      v.x = a.x * (1.0f / (1.0f + expf(-g.x))); v.y = a.y * (1.0f / (1.0f + expf(-g.y)));   // glu_kernel's formula
+      v.z = a.z * (1.0f / (1.0f + expf(-g.z))); v.w = a.w * (1.0f / (1.0f + expf(-g.w)));
+    }
+    *reinterpret_cast<float4*>(dw_xs + r * LD + cc * 4) = v;
+  }
+  float4 wk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) wk[k] = *reinterpret_cast<const float4*>(w + (long long)k * C + c0 + c4 * 4);
+  __syncthreads();
+  float4 acc[FPT];
+#pragma unroll
+  for (int n = 0; n < FPT; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* xr = dw_xs + (fg * FPT) * LD + c4 * 4;
+#pragma unroll
+  for (int j = 0; j < FPT + K - 1; ++j) {
+    const float4 x = *reinterpret_cast<const float4*>(xr + j * LD);
+#pragma unroll
+    for (int n = 0; n < FPT; ++n) {
+      const int k = j - n;   // compile-time after unrolling
+      if (k >= 0 && k < K) {
+        acc[n].x = fmaf(x.x, wk[k].x, acc[n].x); acc[n].y = fmaf(x.y, wk[k].y, acc[n].y);
+        acc[n].z = fmaf(x.z, wk[k].z, acc[n].z); acc[n].w = fmaf(x.w, wk[k].w, acc[n].w);
+      }
+    }
+  }
+  const float4 bb = *reinterpret_cast<const float4*>(bias + c0 + c4 * 4);
+#pragma unroll
+  for (int n = 0; n < FPT; ++n) {
+    const int t = t0 + fg * FPT + n;
+    if (t < N) {
+      float4 v;
+      v.x = swish1(acc[n].x + bb.x); v.y = swish1(acc[n].y + bb.y); v.z = swish1(acc[n].z + bb.z); v.w = swish1(acc[n].w + bb.w);
+      *reinterpret_cast<float4*>(out + ((long long)b * N + t) * C + c0 + c4 * 4) = v;
+    }
+  }
+}
+
 // spec = exp(q[:bins]), phase = sin(q[bins:2 bins]) (V/generator.py:110-111); X = spec * exp(j phase) (stft.py:141)
 __global__ void istft_prep_kernel(const float* __restrict__ q, int ldq, float* __restrict__ specphase, float2* __restrict__ ri,
                                   long long total, int bins) {
@@ -747,6 +806,35 @@ const char* launch_dwconv_swish(const float* in, const float* w, const float* bi
   hipLaunchKernelGGL(dwconv_swish_kernel, dim3((unsigned)((items + 255) / 256), B), dim3(256), 0, s, reinterpret_cast<const float4*>(in),
                      reinterpret_cast<const float4*>(w), reinterpret_cast<const float4*>(bias), reinterpret_cast<float4*>(out), N, C / 4, k);
   return CHECK_LAUNCH("dwconv_swish");
+}
+
+template <int K, int CT>
+static const char* launch_dwglu_cfg(const float* in, const float* w, const float* bias, float* out, int B, int N, int C, hipStream_t s) {
+  const size_t lds = (size_t)(64 + K - 1) * (CT + 4) * sizeof(float);
+  if (lds > 64 * 1024) return "dwconv_glu: LDS tile exceeds 64 KiB";
+  hipLaunchKernelGGL((dwconv_glu_swish_kernel<K, CT>), dim3((unsigned)((N + 63) / 64), (unsigned)(C / CT), (unsigned)B), dim3(256), lds, s, in, w, bias,
+                     out, N, C);
+  return CHECK_LAUNCH("dwconv_glu_swish");
+}
+
+// out = Swish(BN(dwconv_k(GLU(in)))): in [B, N, 2C], out [B, N, C]; scratch [B, N, C] is used only when (k, C) has no fused form
+// (then: launch_glu into scratch, launch_dwconv_swish from it).  fused_out (optional) reports which path ran.
+const char* launch_dwconv_glu_swish(const float* in, const float* w, const float* bias, float* out, float* scratch, int B, int N, int C, int k,
+                                    hipStream_t s, bool* fused_out) {
+  if (!in || !w || !bias || !out || !scratch || in == out) return "dwconv_glu: null or aliased pointer";
+  if (B <= 0 || N <= 0 || C <= 0 || C % 4 || k <= 0 || k % 2 == 0) return "dwconv_glu: channels must be a multiple of 4, kernel odd";
+  if (((uintptr_t)in | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out | (uintptr_t)scratch) & 15) return "dwconv_glu: buffers must be 16-byte aligned";
+  if (B > 65535) return "dwconv_glu: batch exceeds the grid limit";
+  static const bool off = getenv("E2ETTS_DWGLU") && atoi(getenv("E2ETTS_DWGLU")) == 0;   // tuning aid: the two-kernel form
+  if (fused_out) *fused_out = true;
+  if (!off) {
+    if (k == 31 && C % 128 == 0) return launch_dwglu_cfg<31, 128>(in, w, bias, out, B, N, C, s);
+    if (k == 15 && C % 128 == 0) return launch_dwglu_cfg<15, 128>(in, w, bias, out, B, N, C, s);
+    if (k == 7 && C % 64 == 0) return launch_dwglu_cfg<7, 64>(in, w, bias, out, B, N, C, s);
+  }
+  if (fused_out) *fused_out = false;
+  if (const char* m = launch_glu(in, scratch, (long long)B * N, C, s)) return m;
+  return launch_dwconv_swish(scratch, w, bias, out, B, N, C, k, s);
 }
 
 const char* launch_istft(const float* q, int ldq, float* specphase, float* ri, float* wav, int16_t* pcm, int B, long long F, int nfft,

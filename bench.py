@@ -768,35 +768,43 @@ def c5_longform(torch, traffic_json):
     v.load_state_dict(sw.to_torch(sw.make_vocoder_state(cfg, seed=33)))
     eng = v.eval().to(0).engine
     mel = np.random.Generator(np.random.PCG64(7)).standard_normal((1, C5_FRAMES, 80)).astype(np.float32)
-    chunks = [np.ascontiguousarray(mel[:, i:i + C5_CHUNK]) for i in range(0, C5_FRAMES, C5_CHUNK)]
     rec = {"workload": f"48 kHz HiFi-GAN (8x8x4x2, hop 512, width 512), 1 utterance of {C5_FRAMES} frames = {C5_FRAMES * 512 / 48000:.2f} s, "
                        f"streamed in chunks of {C5_CHUNK} frames, PCM fetched per chunk; mel resident on the host", "sample_rate": 48000}
-    run = lambda: sum(p.shape[1] for p in eng.vocoder_stream(chunks, 1, want_pcm=True))
-    for prec in ("bf16", "bf16x3", "fp32"):
-        eng.set_precision(prec)
-        n = run()
-        assert n == C5_FRAMES * 512, n
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
+
+    def one_chunk_size(chunk, table_tag):
+        chunks = [np.ascontiguousarray(mel[:, i:i + chunk]) for i in range(0, C5_FRAMES, chunk)]
+        run = lambda: sum(p.shape[1] for p in eng.vocoder_stream(chunks, 1, want_pcm=True))
+        res = {}
+        for prec in ("bf16", "bf16x3", "fp32"):
+            eng.set_precision(prec)
+            n = run()
+            assert n == C5_FRAMES * 512, n
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                run()
+                ts.append(time.perf_counter() - t0)
+            dt = statistics.median(ts)
+            eng.profile_filter(None)
+            eng.profile_enable(True)
             run()
-            ts.append(time.perf_counter() - t0)
-        dt = statistics.median(ts)
-        eng.profile_filter(None)
-        eng.profile_enable(True)
-        run()
-        torch.cuda.synchronize()
-        st = eng.profile_read()
-        eng.profile_enable(False)
-        dom = max(st, key=lambda s: s["ms"])
-        rl = roofline_of(dom, 1, traffic_json if prec != "bf16" else {}, plain_bf16=(prec == "bf16"))
-        conv = [s for s in st if s["name"].startswith(CONV_CLASSES)]
-        rl["all_conv_tflops"] = round(sum(s["flops"] for s in conv) / max(sum(s["ms"] for s in conv) * 1e-3, 1e-9) / 1e12, 3)
-        rl["kernel_ms_per_pass"] = round(sum(s["ms"] for s in st), 3)
-        rl["traffic"] = None
-        if prec == "bf16":
-            class_table(st, 1, "[c5 bf16] ")
-        rec[prec] = {"ms": dt * 1e3, "real_time_factor": n / 48000 / dt, "samples_per_s": n / dt, "roofline": rl}
+            torch.cuda.synchronize()
+            st = eng.profile_read()
+            eng.profile_enable(False)
+            dom = max(st, key=lambda s: s["ms"])
+            rl = roofline_of(dom, 1, {}, plain_bf16=(prec == "bf16"))
+            conv = [s for s in st if s["name"].startswith(CONV_CLASSES)]
+            rl["all_conv_tflops"] = round(sum(s["flops"] for s in conv) / max(sum(s["ms"] for s in conv) * 1e-3, 1e-9) / 1e12, 3)
+            rl["kernel_ms_per_pass"] = round(sum(s["ms"] for s in st), 3)
+            rl["traffic"] = None
+            if prec == "bf16" and table_tag:
+                class_table(st, 1, table_tag)
+            res[prec] = {"ms": dt * 1e3, "real_time_factor": n / 48000 / dt, "samples_per_s": n / dt, "roofline": rl}
+        return res
+
+    rec.update(one_chunk_size(C5_CHUNK, "[c5 bf16] "))
+    # the same stream in chunks of 2 048 frames (21.8 s of audio per push): fewer, larger launches -- what the chunk size buys
+    rec["chunks_of_2048_frames"] = one_chunk_size(2048, None)
     eng.close()
     return rec
 

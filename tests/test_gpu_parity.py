@@ -860,3 +860,70 @@ def test_runaway_durations_are_rejected_not_wrapped():
         with pytest.raises(ValueError, match="exceeds|unreasonably large"):
             eng.synthesize(ids, lens, spk)
         eng.close()
+
+
+@pytest.mark.parametrize("B", [64, 70])
+def test_ragged_batches_at_and_beyond_the_compact_grid_capacity(B):
+    """Ragged launches find their utterance through a table in the kernel arguments that holds 64 utterances (kernels.h: RowMap,
+    round 3); B = 64 fills it, B = 70 falls back to the padded grid (workgroups beyond an utterance's rows exit).  Either way the valid
+    samples must equal the padded computation bit for bit, in both arithmetic modes, and an utterance must not depend on the batch
+    around it more than the reference's padded batch does -- checked here as ragged == padded only (tiny config, mixed lengths 3 .. 29)."""
+    g = load_golden("tiny_b3")
+    cfg, eng = engine_for(g, "tiny_b3")
+    rng = np.random.Generator(np.random.PCG64(64 + B))
+    lens = rng.integers(3, 30, size=B).astype(np.int64)
+    lens[0] = 29
+    L = int(lens.max())
+    ids = np.zeros((B, L), np.int64)
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(4, 131, size=n)
+    spk = np.array([1], np.int64)
+    hop = cfg["audio"]["stft"]["hop_length"]
+    for prec in PRECISIONS:
+        eng.set_precision(prec)
+        eng.set_ragged(False)
+        full, mel_lens, T = eng.synthesize(ids, lens, spk)
+        eng.set_ragged(True)
+        rag, mel_lens2, T2 = eng.synthesize(ids, lens, spk)
+        assert T == T2 and np.array_equal(mel_lens, mel_lens2) and int(mel_lens.min()) < T
+        for b, n in enumerate(mel_lens * hop):
+            np.testing.assert_array_equal(rag[b, :n], full[b, :n])
+    eng.set_ragged(True)
+
+
+@pytest.mark.parametrize("name", ["tiny_cf_b3", "full_cf_b2"])
+def test_fused_glu_depthwise_kernel_is_bit_identical_to_the_two_kernel_form(tmp_path, name):
+    """Conformer convolution module: dwconv_glu_swish_kernel (GLU of a tile staged in LDS once, weights in registers, rows streamed past the
+    accumulators; k = 7 at 64 channels in the tiny config, k = 31 at 384 in the default one) against glu_kernel + dwconv_swish_kernel
+    (E2ETTS_DWGLU=0, read once per process: a child runs it): same products added in the same order, so the mel must be equal bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    g = load_golden(name)
+    cfg, eng = engine_for(g, name)
+    eng.set_precision("fp32")
+    spk = np.array([int(g["speaker"])], np.int64)
+    d, p, e = (float(x) for x in g["controls"])
+    r = eng.acoustic(g["ids"], g["lens"], spk, d, p, e, want=("dur", "mel_lens"))
+    _, mel_post = eng.fetch_mel(r["B"], r["T"], mel=False)
+    script = tmp_path / "dwglu_child.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "from conftest import load_golden, states_for\n"
+        "from e2e_tts_amd import config as cfgmod\n"
+        "from e2e_tts_amd.runtime import engine_from_states\n"
+        f"g = load_golden({name!r}); cfg, ac, voc = states_for(g, {name!r})\n"
+        "eng = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)\n"
+        "eng.set_precision('fp32')\n"
+        "spk = np.array([int(g['speaker'])], np.int64); d, p, e = (float(x) for x in g['controls'])\n"
+        "r = eng.acoustic(g['ids'], g['lens'], spk, d, p, e, want=('dur', 'mel_lens'))\n"
+        "_, mel_post = eng.fetch_mel(r['B'], r['T'], mel=False)\n"
+        "np.savez(sys.argv[1], mel_post=mel_post, dur=r['dur'])\n")
+    out = tmp_path / "dwglu.npz"
+    rr = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, E2ETTS_DWGLU="0"), capture_output=True, text=True, timeout=900)
+    assert rr.returncode == 0, rr.stderr[-3000:]
+    o = np.load(out)
+    np.testing.assert_array_equal(o["dur"], r["dur"])
+    np.testing.assert_array_equal(o["mel_post"], mel_post)

@@ -41,6 +41,25 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Key SEGMENTS (round 3).  The exact-fp32 attention kernels run the online softmax per segment of ATT_SEG_CHUNKS x 32 keys -- each segment
+// from scratch: running max -inf, sum 0, O 0 -- and merge the finished segments in key order:
+//     m' = max(m, m_s);  a = exp(m - m'), b = exp(m_s - m');  l' = l a + l_s b;  O' = O a + O_s b
+// (explicit mul / fma: every kernel that merges produces the same bits).  A sequence of up to one segment (the encoder) is computed exactly as
+// before (the merge of a single segment multiplies by exp(-inf) = 0 and exp(0) = 1).  What the segments buy: they are independent until
+// the merge, so a SMALL grid -- the B = 1 latency path, 24 workgroups walking 24 chunks each -- can hand every segment to a workgroup of
+// its own (attention_split_kernel with par_nseg > 0 writes (O_s, m_s, l_s) to a workspace, attention_combine_kernel merges them), while a
+// large grid keeps one workgroup per query block that merges in registers: the same operations either way, hence the same bits at every
+// batch size (tests: a B = 1 utterance equals its row of the B = 32 batch).
+constexpr int ATT_SEG_CHUNKS = 8;
+__device__ __forceinline__ void seg_merge_ml(float& m, float& l, const float m_s, const float l_s, float& a, float& b) {
+  const float m_new = fmaxf(m, m_s);
+  a = expf(m - m_new);      // first segment: m = -inf -> 0
+  b = expf(m_s - m_new);
+  l = __fmaf_rn(l_s, b, __fmul_rn(l, a));
+  m = m_new;
+}
+__device__ __forceinline__ float seg_merge_o(const float o, const float o_s, const float a, const float b) { return __fmaf_rn(o_s, b, __fmul_rn(o, a)); }
+
 // (utterance b, head, query block qblk) of this workgroup.  Padded grid: (x, y, z) = (query block, head, utterance).  Compact grid of a
 // ragged batch whose lengths the host knows (kernels.h: RowMap): 1-D, utterance b owns ceil(len_b / rows) x n_head consecutive blocks,
 // heads fastest -- no block of padded queries exists (their output rows keep what they held: every consumer masks them, engine.hip).
@@ -101,9 +120,18 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  // (o, m_run, l_run) accumulate the current key segment, (ot, m_tot, l_tot) the merged segments before it -- attention_split_kernel's order
+  f32x16 ot[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  float m_tot = -INFINITY, l_tot = 0.f;
 
   const int nchunks = (len + 31) / 32;
-  for (int kc = 0; kc < nchunks; ++kc) {
+  for (int sg0 = 0; sg0 < nchunks; sg0 += ATT_SEG_CHUNKS) {   // (two loops: see attention_split_kernel)
+  const int sg1 = min(nchunks, sg0 + ATT_SEG_CHUNKS);
+  for (int kc = sg0; kc < sg1; ++kc) {
     __syncthreads();
     for (int i = tid; i < 32 * (DK / 4); i += 256) {
       const int r = i / (DK / 4), c = (i % (DK / 4)) * 4;
@@ -180,6 +208,35 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
       }
     }
   }
+    {   // the key segment ends (see ATT_SEG_CHUNKS): merge it, start the next from scratch
+      if (sg0 == 0) {   // the first segment is the total so far
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[d][r] = o[d][r];
+        m_tot = m_run;
+        l_tot = l_run;
+      } else {
+        float ma, mb;
+        seg_merge_ml(m_tot, l_tot, m_run, l_run, ma, mb);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[d][r] = seg_merge_o(ot[d][r], o[d][r], ma, mb);
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+      m_run = -INFINITY;
+      l_run = 0.f;
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = ot[d][r];
+  l_run = l_tot;
 
   // O^T tile d: column = query (lane & 31), row = head-dim offset (r & 3) + 8 (r >> 2) + 4 lh -> 4 x float4 per tile
   const int q = q0 + li;
@@ -212,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 // request the next chunk's K / V rows before this chunk's arithmetic (the staging round trip was exposed once per chunk).
 template <int DK, int QT>
 __global__ __launch_bounds__(QT * 128, 2) void attention_split_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                 const int32_t* __restrict__ lens, int N, int H, float temperature, const RowMap rm) {
+                                                                 const int32_t* __restrict__ lens, int N, int H, float temperature, const RowMap rm,
+                                                                 float* __restrict__ ws_o, float* __restrict__ ws_ml, const int par_nseg) {
   constexpr int LDS_LD = DK + 4;
   constexpr int DH = DK / 2;    // head-dim channels per wavefront
   constexpr int DTH = DH / 32;  // its 32-wide tiles
@@ -229,8 +287,14 @@ __global__ __launch_bounds__(QT * 128, 2) void attention_split_kernel(const floa
   const int li = lane & 31, lh = lane >> 5;
   const int qt = wave >> 1, part = wave & 1;
   ATT_BLOCK_OF_GRID(QT * 32)
+  int seg_id = 0;   // par_nseg > 0 (padded grids only): x = query block x segments; this workgroup computes ONE key segment's partial result
+  if (par_nseg > 0) {
+    seg_id = qblk % par_nseg;
+    qblk /= par_nseg;
+  }
   const int q0 = qblk * (QT * 32) + qt * 32;
   const int len = min(lens ? lens[b] : N, N);
+  if (par_nseg > 0 && qblk * (QT * 32) >= len) return;   // attention_combine_kernel writes the zero rows
   if (qblk * (QT * 32) >= len) {  // a tile of padded queries only: their rows are zero (padded grids)
     for (int i = tid; i < QT * 32 * (DK / 4); i += NTH) {
       const int q = qblk * (QT * 32) + i / (DK / 4);
@@ -286,12 +350,26 @@ __global__ __launch_bounds__(QT * 128, 2) void attention_split_kernel(const floa
   };
 
   const int nchunks = (len + 31) / 32;
-  fetch(0);
-  for (int kc = 0; kc < nchunks; ++kc) {
+  // (o, m_run, l_run) accumulate the CURRENT key segment; (ot, m_tot, l_tot) the merged segments before it (serial form)
+  const int kc_begin = par_nseg > 0 ? seg_id * ATT_SEG_CHUNKS : 0;
+  const int kc_end = par_nseg > 0 ? min(nchunks, (seg_id + 1) * ATT_SEG_CHUNKS) : nchunks;
+  if (kc_begin >= kc_end) return;   // a segment beyond this utterance's keys (uniform for the workgroup, before any barrier)
+  f32x16 ot[DTH];
+#pragma unroll
+  for (int d = 0; d < DTH; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  float m_tot = -INFINITY, l_tot = 0.f;
+  fetch(kc_begin);
+  // (two loops on purpose: the inner one never touches `ot`, so the register allocator may park the merged segments outside it -- as one
+  // flat loop with the merge under a condition it spilled and reloaded them in EVERY chunk, and each scratch access drains the K / V prefetch)
+  for (int sg0 = kc_begin; sg0 < kc_end; sg0 += ATT_SEG_CHUNKS) {
+  const int sg1 = min(kc_end, sg0 + ATT_SEG_CHUNKS);
+  for (int kc = sg0; kc < sg1; ++kc) {
     lds_barrier();  // every wavefront is done with the previous chunk's K / V
     stash(kc);
     lds_barrier();
-    if (kc + 1 < nchunks) fetch(kc + 1);
+    if (kc + 1 < kc_end) fetch(kc + 1);
 
     // partial S^T over this wavefront's half of the head dimension
     f32x16 s;
@@ -350,8 +428,50 @@ __global__ __launch_bounds__(QT * 128, 2) void attention_split_kernel(const floa
       }
     }
   }
+    if (par_nseg == 0) {   // the segment ends: merge it, start the next one from scratch
+      if (sg0 == kc_begin) {   // the first segment IS the total so far (every merging kernel assigns here: no parked registers to fetch)
+#pragma unroll
+        for (int d = 0; d < DTH; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[d][r] = o[d][r];
+        m_tot = m_run;
+        l_tot = l_run;
+      } else {
+        float ma, mb;
+        seg_merge_ml(m_tot, l_tot, m_run, l_run, ma, mb);
+#pragma unroll
+        for (int d = 0; d < DTH; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[d][r] = seg_merge_o(ot[d][r], o[d][r], ma, mb);
+      }
+#pragma unroll
+      for (int d = 0; d < DTH; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+      m_run = -INFINITY;
+      l_run = 0.f;
+    }
+  }
 
   const int q = q0 + li;
+  if (par_nseg > 0) {  // this segment's unnormalised partial result: O_s [.., N, DK] and (m_s, l_s) [.., N, 2] per (utterance, head, segment)
+    if (q < N) {
+      const long long row = (((long long)b * (H / DK) + head) * par_nseg + seg_id) * N + q;
+      float* orow = ws_o + row * DK + part * DH + 4 * lh;
+#pragma unroll
+      for (int d = 0; d < DTH; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(orow + d * 32 + 8 * g) = make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
+      if (part == 0 && lh == 0) *reinterpret_cast<float2*>(ws_ml + row * 2) = make_float2(m_run, l_run);
+    }
+    return;
+  }
+#pragma unroll
+  for (int d = 0; d < DTH; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = ot[d][r];
+  l_run = l_tot;
   if (q < N) {
     const bool valid = q < len;
     const float inv = valid ? 1.0f / l_run : 0.f;
@@ -368,6 +488,41 @@ __global__ __launch_bounds__(QT * 128, 2) void attention_split_kernel(const floa
         *reinterpret_cast<float4*>(orow + d * 32 + 8 * g) = v;
       }
   }
+}
+
+// Merges the key segments attention_split_kernel left in the workspace (par_nseg > 0): per (utterance, head, query) the segments in key
+// order with seg_merge_*, then the normalisation and the zero rows of padded queries, as the kernels' own epilogues write them.
+__global__ void attention_combine_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, float* __restrict__ out,
+                                         const int32_t* __restrict__ lens, int N, int H, int DK, int par_nseg, long long total4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, q, head, float4 of the head dimension)
+  if (i >= total4) return;
+  const int d4 = DK / 4, nh = H / DK;
+  const int c4 = (int)(i % d4);
+  const int head = (int)((i / d4) % nh);
+  const long long bq = i / ((long long)d4 * nh);
+  const int q = (int)(bq % N), b = (int)(bq / N);
+  const int len = min(lens ? lens[b] : N, N);
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < len) {
+    const int nseg = ((len + 31) / 32 + ATT_SEG_CHUNKS - 1) / ATT_SEG_CHUNKS;
+    float m = -INFINITY, l = 0.f;
+    for (int sg = 0; sg < nseg; ++sg) {
+      const long long row = (((long long)b * nh + head) * par_nseg + sg) * N + q;
+      const float2 ml = *reinterpret_cast<const float2*>(ws_ml + row * 2);
+      const float4 os = *reinterpret_cast<const float4*>(ws_o + row * DK + c4 * 4);
+      if (sg == 0) {   // the first segment is the total so far (as in the kernels that merge in registers)
+        m = ml.x; l = ml.y; o = os;
+      } else {
+        float ma, mb;
+        seg_merge_ml(m, l, ml.x, ml.y, ma, mb);
+        o.x = seg_merge_o(o.x, os.x, ma, mb); o.y = seg_merge_o(o.y, os.y, ma, mb);
+        o.z = seg_merge_o(o.z, os.z, ma, mb); o.w = seg_merge_o(o.w, os.w, ma, mb);
+      }
+    }
+    const float inv = 1.0f / l;
+    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+  }
+  *reinterpret_cast<float4*>(out + ((long long)b * N + q) * H + head * DK + c4 * 4) = o;
 }
 
 // ---- Conformer: relative-position attention (reference U/blocks/conformer.py:399-440), fp32.  Same flash-style structure and MFMA
@@ -1276,8 +1431,13 @@ const char* launch_rel_attention(const float* qkv, const float* pos, int pos_row
   return err == hipSuccess ? nullptr : hipGetErrorString(err);
 }
 
+size_t attention_workspace_bytes(int B, int N, int H, int n_head) {
+  const long long nseg = ((N + 31) / 32 + ATT_SEG_CHUNKS - 1) / ATT_SEG_CHUNKS;
+  return (size_t)((long long)B * n_head * nseg * N * (H / n_head + 2) * 4);
+}
+
 const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head, int x3,
-                             hipStream_t s, const int32_t* lens_host) {
+                             hipStream_t s, const int32_t* lens_host, float* ws, size_t ws_bytes) {
   if (!qkv || !out) return "attention: null pointer";
   if (B <= 0 || N <= 0 || n_head <= 0 || H % n_head) return "attention: bad dims";
   if (((uintptr_t)qkv | (uintptr_t)out) & 15) return "attention: buffers must be 16-byte aligned";
@@ -1341,11 +1501,30 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
     return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
   }
   if (split) {
-    const dim3 gc = shape(gs, 64);
+    dim3 gc = shape(gs, 64);
+    // Small padded grids (the B = 1 latency path): every key segment of a query block in a workgroup of its own, merged by
+    // attention_combine_kernel -- the same operations as the in-register merge, so the same bits (ATT_SEG_CHUNKS).  B = 1, T = 768: 24
+    // workgroups walking 24 chunks -> 72 walking 8, 133 -> ~55 us per decoder layer.  E2ETTS_ATT_PAR=0: never (tuning aid).
+    static const bool par_on = !(getenv("E2ETTS_ATT_PAR") && atoi(getenv("E2ETTS_ATT_PAR")) == 0);
+    const int nseg = ((N + 31) / 32 + ATT_SEG_CHUNKS - 1) / ATT_SEG_CHUNKS;
+    int par_nseg = 0;
+    float *ws_o = nullptr, *ws_ml = nullptr;
+    if (par_on && rm.n == 0 && nseg >= 2 && ws && ws_bytes >= attention_workspace_bytes(B, N, H, n_head) && (((uintptr_t)ws) & 15) == 0 &&
+        (long long)gs.x * gs.y * gs.z <= 128 && (long long)gs.x * nseg < (1LL << 31)) {
+      par_nseg = nseg;
+      ws_o = ws;
+      ws_ml = ws + (long long)B * n_head * nseg * N * dk;
+      gc = dim3(gs.x * nseg, gs.y, gs.z);
+    }
     switch (dk) {
-      case 64: hipLaunchKernelGGL((attention_split_kernel<64, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
-      case 128: hipLaunchKernelGGL((attention_split_kernel<128, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
-      default: hipLaunchKernelGGL((attention_split_kernel<192, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm); break;
+      case 64: hipLaunchKernelGGL((attention_split_kernel<64, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm, ws_o, ws_ml, par_nseg); break;
+      case 128: hipLaunchKernelGGL((attention_split_kernel<128, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm, ws_o, ws_ml, par_nseg); break;
+      default: hipLaunchKernelGGL((attention_split_kernel<192, 2>), gc, dim3(256), 0, s, qkv, out, lens, N, H, temperature, rm, ws_o, ws_ml, par_nseg); break;
+    }
+    if (hipGetLastError() != hipSuccess) return "attention: launch failed";
+    if (par_nseg > 0) {
+      const long long total4 = (long long)B * N * (H / 4);
+      hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, ws_o, ws_ml, out, lens, N, H, dk, par_nseg, total4);
     }
     return hipGetLastError() == hipSuccess ? nullptr : "attention: launch failed";
   }

@@ -110,7 +110,7 @@ struct e2etts_engine {
   int fuse_pairs = 2;  // e2etts_set_fused_resblocks: 0 off, 1 pairs, 2 pairs + whole k = 3 ResBlocks
 
   // workspace
-  DevBuf ids, lens64, lens32, spk, xa, xb, xs, xp, tmp, qkv, att, hid, p1, p2;
+  DevBuf ids, lens64, lens32, spk, xa, xb, xs, xp, tmp, qkv, att, hid, p1, p2, attws;
   DevBuf logd, durf, cum, mel64, mel32, posbuf, ppred, epred, pidx, eidx;
   DevBuf dx, dxb, mel, melpost, pn1, pn2;
   DevBuf melin, v0, v1, v2, v3, wav, pcm;
@@ -639,7 +639,14 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     {
       const double fl = 4.0 * B * c.n_head * (double)N * N * (H / c.n_head);
       ProfScope ps(e, sx ? "attention_x3" : "attention", fl, 4.0 * 4.0 * B * N * H);
-      KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, sx ? 1 : 0, e->stream, act_host));
+      float* aws = nullptr;   // workspace for the parallel key segments of small fp32 grids (attention.hip); 3.6 MB at B = 1, T = 768
+      size_t aws_bytes = 0;
+      if (!sx && !act_host && (long long)B * ((N + 63) / 64) * c.n_head <= 128 && N > 32 * 8) {
+        aws_bytes = attention_workspace_bytes(B, N, H, c.n_head);
+        RET(ensure(e, e->attws, aws_bytes));
+        aws = ptr<float>(e->attws);
+      }
+      KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, sx ? 1 : 0, e->stream, act_host, aws, aws_bytes));
     }
     // fc + residual (:238-239), LayerNorm eps 1e-5, masked_fill (:182-183)
     p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;

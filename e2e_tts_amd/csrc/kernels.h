@@ -85,8 +85,11 @@ const char* launch_conv_rows(const ConvParams& p, hipStream_t s);
 // out [B, N, H]; query rows >= lens[b] are written as 0 (they are zeroed after the LayerNorm anyway).
 // lens_host: the same B lengths in host memory (optional): the grid then holds only the query blocks that exist (RowMap), and the output
 // rows of queries >= lens[b] beyond the last block keep their old contents instead of being zeroed.
+// ws (optional, attention_workspace_bytes(B, N, H, n_head) bytes, 16-byte aligned): lets small padded fp32 grids compute the key segments
+// of a query block in workgroups of their own and merge them in a second launch (same bits as the in-register merge).
 const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head, int x3,
-                             hipStream_t s, const int32_t* lens_host = nullptr);
+                             hipStream_t s, const int32_t* lens_host = nullptr, float* ws = nullptr, size_t ws_bytes = 0);
+size_t attention_workspace_bytes(int B, int N, int H, int n_head);
 
 // y[row, :] = LayerNorm(x[row, :]) * gamma + beta; rows t >= lens[b] -> 0 when lens != null (C <= 1024, C % 4 == 0)
 const char* launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, const int32_t* lens,

@@ -927,3 +927,44 @@ def test_fused_glu_depthwise_kernel_is_bit_identical_to_the_two_kernel_form(tmp_
     o = np.load(out)
     np.testing.assert_array_equal(o["dur"], r["dur"])
     np.testing.assert_array_equal(o["mel_post"], mel_post)
+
+
+def test_parallel_key_segments_match_the_in_register_merge(tmp_path):
+    """Exact-fp32 attention runs its online softmax per segment of 256 keys and merges the segments in key order (attention.hip,
+    ATT_SEG_CHUNKS).  On a small padded grid -- this B = 1, T = 768 fixture: 24 query blocks -- every segment gets a workgroup of its own
+    and attention_combine_kernel merges them; a large grid (and the child process here, E2ETTS_ATT_PAR=0) merges in registers.  The same
+    operations in the same order: mel and PCM must be equal bit for bit, and both still meet the fixture the reference produced."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    g = load_golden("c2_latency")
+    cfg, eng = engine_for(g, "c2_latency")
+    eng.set_precision("fp32")
+    spk = np.array([int(g["speaker"])], np.int64)
+    r = eng.acoustic(g["ids"], g["lens"], spk, want=("dur", "mel_lens"))
+    assert r["T"] > 256 and r["B"] == 1
+    _, mel_post = eng.fetch_mel(r["B"], r["T"], mel=False)
+    wav, pcm = eng.vocoder(None, r["B"], r["T"], pcm=True)
+    assert mean_l1(mel_post, g["mel_post"]) < 1e-4
+    script = tmp_path / "attpar_child.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "from conftest import load_golden, states_for\n"
+        "from e2e_tts_amd import config as cfgmod\n"
+        "from e2e_tts_amd.runtime import engine_from_states\n"
+        "g = load_golden('c2_latency'); cfg, ac, voc = states_for(g, 'c2_latency')\n"
+        "eng = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)\n"
+        "eng.set_precision('fp32')\n"
+        "spk = np.array([int(g['speaker'])], np.int64)\n"
+        "r = eng.acoustic(g['ids'], g['lens'], spk, want=('dur', 'mel_lens'))\n"
+        "_, mel_post = eng.fetch_mel(r['B'], r['T'], mel=False)\n"
+        "wav, pcm = eng.vocoder(None, r['B'], r['T'], pcm=True)\n"
+        "np.savez(sys.argv[1], mel_post=mel_post, pcm=pcm)\n")
+    out = tmp_path / "attpar.npz"
+    rr = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, E2ETTS_ATT_PAR="0"), capture_output=True, text=True, timeout=900)
+    assert rr.returncode == 0, rr.stderr[-3000:]
+    o = np.load(out)
+    np.testing.assert_array_equal(o["mel_post"], mel_post)
+    np.testing.assert_array_equal(o["pcm"], pcm)

@@ -193,7 +193,7 @@ def cpu_baseline(cfg, stats, ac_state, voc_state, ids_batch):
     dt0, bs = run(batch_ids, best[0], usable)      # warm-up of the batch shapes
     t_whole = [run(batch_ids, best[0], usable)[0] for _ in range(CPU_BATCH_RUNS)] if dt0 < 40 else [dt0]
     legs["one_call"] = {"threads": usable, "median_s": round(statistics.median(t_whole), 3)}
-    per_task = max(1, min(best[1], usable))
+    per_task = max(1, min(best[1], max(usable // 2, 1)))   # at least two workers when there are two CPUs
     workers = max(1, min(nb, usable // per_task))
 
     def pool_run():

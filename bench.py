@@ -658,11 +658,16 @@ def main():
     # ---- config 4 beside the headline, at every N (every rank takes part; rank 0 reports)
     if extras:
         k4 = 2 if not stub else 1
-        el4, per4, s4, st4 = run_c4(256, k4, 1)
-        if rank == 0:
-            out["c4_sharded"] = c4_record(el4, per4, s4, st4, k4, 256)
-            log(f"[bench] c4_sharded: {out['c4_sharded']['samples_per_s']:,.0f} valid samples/s, {out['c4_sharded']['ms_per_pass']:.1f} ms per pass of 256 "
-                f"utterances on {world} rank(s), balance {out['c4_sharded']['balance_max_over_mean']}")
+        try:   # an extra must not take the headline line down with it (an error raised on every rank alike leaves the ranks in step)
+            el4, per4, s4, st4 = run_c4(256, k4, 1)
+            if rank == 0:
+                out["c4_sharded"] = c4_record(el4, per4, s4, st4, k4, 256)
+                log(f"[bench] c4_sharded: {out['c4_sharded']['samples_per_s']:,.0f} valid samples/s, {out['c4_sharded']['ms_per_pass']:.1f} ms per pass of 256 "
+                    f"utterances on {world} rank(s), balance {out['c4_sharded']['balance_max_over_mean']}")
+        except Exception as ex:
+            if rank == 0:
+                out["c4_sharded"] = {"error": repr(ex)}
+            log(f"[bench] rank {rank}: c4_sharded failed: {ex!r}")
     if rank == 0:
         if world == 1 and extras and not stub:
             # (1) the same steps with ids / PCM resident in HBM (no PCIe in the timed region)

@@ -47,3 +47,18 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # value and ms_per_step describe the same timed region
     samples = 4 * 768 * 256
     assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_bench_helpers_without_a_gpu():
+    """Host-only pieces of bench.py: the CPUs a process may really use (affinity mask / cgroup quota, not os.cpu_count()), BASELINE
+    config 3's length list and config 4's utterance list (config 3's lengths x 8, the same on every rank)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n, why = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1) and isinstance(why, str) and why
+    lens = bench.mixed_lengths(32)
+    assert lens.min() == 40 and lens.max() == 200 and int(lens.sum()) * 6 == 23040 and len(lens) == 32
+    a, b = bench.c4_id_lists(256), bench.c4_id_lists(256)
+    assert a == b and len(a) == 256 and sum(len(x) for x in a) * 6 == 8 * 23040
+    assert sorted(len(x) for x in a[:32]) == sorted(lens.tolist())
+    assert all(4 <= t <= 130 for x in a[:8] for t in x)

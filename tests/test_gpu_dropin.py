@@ -315,3 +315,32 @@ def test_gpu_tempo_kernel_follows_the_host_wsola():
     with pytest.raises(TypeError):
         eng.tempo(x.astype(np.float32), 1.5, sr)
     eng.close()
+
+
+def test_gather_pcm_tensor_path_over_rccl_single_rank():
+    """dist.gather_pcm's collectives -- all-reduce of the table / payload sizes, all-gather of the (index, length) tables, gather of the
+    flat byte payload on the DEVICE, one copy back into page-locked memory -- on a one-rank RCCL group (the only RCCL this one-GPU box
+    offers; world-size-2 runs of the same code use gloo in tests/test_dist_gloo.py).  A child process, so that this process's
+    torch.distributed state stays untouched."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from e2e_tts_amd import dist as edist\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29641', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "rng = np.random.Generator(np.random.PCG64(5))\n"
+        "local = [(i, rng.integers(-32768, 32767, size=int(n)).astype(np.int16)) for i, n in zip((3, 0, 2, 1), (7, 12001, 1, 256))]\n"
+        "st = {}\n"
+        "out = edist.gather_pcm(local, dst=0, device='cuda:0', stats=st, _force_collectives=True)\n"
+        "assert [k for k, _ in out] == [0, 1, 2, 3]\n"
+        "want = dict(local)\n"
+        "for k, pcm in out: assert pcm.dtype == np.int16 and np.array_equal(pcm, want[k])\n"
+        "assert st['samples_per_rank'] == [7 + 12001 + 1 + 256]\n"
+        "assert edist.gather_pcm([], dst=0, device='cuda:0', _force_collectives=True) == []\n"
+        "dist.destroy_process_group(); print('ok')\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]

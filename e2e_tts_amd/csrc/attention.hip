@@ -1431,6 +1431,14 @@ const char* launch_rel_attention(const float* qkv, const float* pos, int pos_row
   return err == hipSuccess ? nullptr : hipGetErrorString(err);
 }
 
+// largest padded grid (64-query workgroups, before the segment split) that computes its key segments in parallel; E2ETTS_ATT_PAR_MAX (tuning aid)
+long long attention_par_max_grid() {
+  // default: up to one round of the serial form's workgroups (2 per CU).  Same box, T = 768: B = 8 (192 workgroups) 1.12 -> 1.04 ms/step,
+  // B = 32 (768) 2.41 -> 2.47: above one round the serial form already fills the chip and the workspace round trip costs more than it buys
+  static const long long v = getenv("E2ETTS_ATT_PAR_MAX") ? atoll(getenv("E2ETTS_ATT_PAR_MAX")) : 512;
+  return v;
+}
+
 size_t attention_workspace_bytes(int B, int N, int H, int n_head) {
   const long long nseg = ((N + 31) / 32 + ATT_SEG_CHUNKS - 1) / ATT_SEG_CHUNKS;
   return (size_t)((long long)B * n_head * nseg * N * (H / n_head + 2) * 4);
@@ -1510,7 +1518,7 @@ const char* launch_attention(const float* qkv, float* out, const int32_t* lens, 
     int par_nseg = 0;
     float *ws_o = nullptr, *ws_ml = nullptr;
     if (par_on && rm.n == 0 && nseg >= 2 && ws && ws_bytes >= attention_workspace_bytes(B, N, H, n_head) && (((uintptr_t)ws) & 15) == 0 &&
-        (long long)gs.x * gs.y * gs.z <= 128 && (long long)gs.x * nseg < (1LL << 31)) {
+        (long long)gs.x * gs.y * gs.z <= attention_par_max_grid() && (long long)gs.x * nseg < (1LL << 31)) {
       par_nseg = nseg;
       ws_o = ws;
       ws_ml = ws + (long long)B * n_head * nseg * N * dk;

@@ -641,7 +641,7 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
       ProfScope ps(e, sx ? "attention_x3" : "attention", fl, 4.0 * 4.0 * B * N * H);
       float* aws = nullptr;   // workspace for the parallel key segments of small fp32 grids (attention.hip); 3.6 MB at B = 1, T = 768
       size_t aws_bytes = 0;
-      if (!sx && !act_host && (long long)B * ((N + 63) / 64) * c.n_head <= 128 && N > 32 * 8) {
+      if (!sx && !act_host && (long long)B * ((N + 63) / 64) * c.n_head <= attention_par_max_grid() && N > 32 * 8) {
         aws_bytes = attention_workspace_bytes(B, N, H, c.n_head);
         RET(ensure(e, e->attws, aws_bytes));
         aws = ptr<float>(e->attws);

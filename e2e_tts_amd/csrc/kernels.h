@@ -90,6 +90,7 @@ const char* launch_conv_rows(const ConvParams& p, hipStream_t s);
 const char* launch_attention(const float* qkv, float* out, const int32_t* lens, int B, int N, int H, int n_head, int x3,
                              hipStream_t s, const int32_t* lens_host = nullptr, float* ws = nullptr, size_t ws_bytes = 0);
 size_t attention_workspace_bytes(int B, int N, int H, int n_head);
+long long attention_par_max_grid();
 
 // y[row, :] = LayerNorm(x[row, :]) * gamma + beta; rows t >= lens[b] -> 0 when lens != null (C <= 1024, C % 4 == 0)
 const char* launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, const int32_t* lens,

@@ -192,7 +192,11 @@ int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decod
  * ragged != 0 it therefore skips, layer by layer, the rows of shorter utterances that no valid sample depends on (rows past
  * mel_len + receptive-field halo), instead of computing the whole padded batch as the reference does.  Valid samples are
  * bit-identical either way; what lies beyond them in the padded PCM rows is then unspecified.  e2etts_acoustic /
- * e2etts_vocoder always compute the full padded tensors (their padded rows match the reference's). */
+ * e2etts_vocoder always compute the full padded tensors (their padded rows match the reference's).
+ * The frame level (decoder, postnet, vocoder) is skipped from the mel lengths the engine computes itself; the phoneme level (encoder,
+ * predictors) additionally when `lens` is HOST memory (the launch grids are built from the lengths on the host; with `lens` in device
+ * memory the phoneme level computes the padded batch -- same results).  Batches of up to 64 utterances launch grids without idle
+ * workgroups; larger ones still skip the rows but keep the padded grid. */
 int e2etts_set_ragged(e2etts_engine* engine, int enable);
 
 /* Fused ResBlocks (bf16 modes).  level 1: each (conv k, dilation d -> leaky ReLU -> conv k -> + x) pair of HiFi-GAN's ResBlock1

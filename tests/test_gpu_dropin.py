@@ -322,15 +322,19 @@ def test_gather_pcm_tensor_path_over_rccl_single_rank():
     flat byte payload on the DEVICE, one copy back into page-locked memory -- on a one-rank RCCL group (the only RCCL this one-GPU box
     offers; world-size-2 runs of the same code use gloo in tests/test_dist_gloo.py).  A child process, so that this process's
     torch.distributed state stays untouched."""
+    import socket
     import subprocess
     import sys
     from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     code = (
         "import sys, numpy as np, torch, torch.distributed as dist\n"
         f"sys.path.insert(0, {ROOT!r})\n"
         "from e2e_tts_amd import dist as edist\n"
         "torch.cuda.set_device(0)\n"
-        "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29641', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        f"dist.init_process_group('nccl', init_method='tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
         "rng = np.random.Generator(np.random.PCG64(5))\n"
         "local = [(i, rng.integers(-32768, 32767, size=int(n)).astype(np.int16)) for i, n in zip((3, 0, 2, 1), (7, 12001, 1, 256))]\n"
         "st = {}\n"

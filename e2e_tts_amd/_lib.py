@@ -83,6 +83,8 @@ def load_library() -> C.CDLL:
     lib.e2etts_set_precision.argtypes = [P, I, I]
     lib.e2etts_set_ragged.restype = I
     lib.e2etts_set_ragged.argtypes = [P, I]
+    lib.e2etts_debug_poison_workspace.restype = I
+    lib.e2etts_debug_poison_workspace.argtypes = [P]
     lib.e2etts_set_fused_resblocks.restype = I
     lib.e2etts_set_fused_resblocks.argtypes = [P, I]
     lib.e2etts_profile_enable.restype = I
@@ -105,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "e2etts_version", "e2etts_last_error", "e2etts_create", "e2etts_destroy", "e2etts_load_weights", "e2etts_acoustic",
     "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
     "e2etts_fetch_wav", "e2etts_vocoder_stream_begin", "e2etts_vocoder_stream_push", "e2etts_vocoder_stream_fetch",
-    "e2etts_set_precision", "e2etts_set_ragged", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_filter", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
+    "e2etts_set_precision", "e2etts_set_ragged", "e2etts_debug_poison_workspace", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_filter", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
     "e2etts_load_weights_bcast", "e2etts_order_after", "e2etts_tempo",
 ]
 
@@ -369,6 +371,11 @@ class Engine:
     def set_ragged(self, on: bool = True):
         """synthesize(): skip the rows of shorter utterances that no valid sample depends on (default on)."""
         self._check(self.lib.e2etts_set_ragged(self._h, 1 if on else 0), "e2etts_set_ragged")
+
+    @_locked
+    def poison_workspace(self):
+        """Test hook: fill the activation workspaces with a large finite pattern (ragged-mode tests: nothing valid may depend on stale rows)."""
+        self._check(self.lib.e2etts_debug_poison_workspace(self._h), "e2etts_debug_poison_workspace")
 
     @_locked
     def set_fused_resblocks(self, on=True):

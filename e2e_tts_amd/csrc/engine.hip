@@ -1053,31 +1053,37 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     if (e->voc_precision != E2ETTS_PRECISION_FP32 && w.wx3) { q.w = w.wx3; q.x3 = e->voc_precision; }
     else { q.w = w.w; q.x3 = 0; }
   };
-  // Ragged mode: utterance b needs output frames < mel_len + halo only (halo = receptive field of the whole generator in
-  // frames); each stage computes those frames at its own rate.  What lies beyond is stale but finite and out of reach.
+  // Ragged mode: the layers of stage i compute rows < mel_len * rate_i + halo_i only (host_logic.h: vocoder_stage_halo_rows -- the
+  // reach of what is still to come, in that stage's rows: 12 frames after conv_pre, 76 / 109 / 94 / 63 rows in the four stages of
+  // HiFi-GAN V1).  What lies beyond is stale but finite and out of the reach of every valid sample.
   const int32_t* act_stage[E2ETTS_MAX_STAGES + 1] = {nullptr};
   const int32_t* act_stage_h[E2ETTS_MAX_STAGES + 1] = {nullptr};  // the same limits in host memory (compact grids), when the caller has the lengths there
+  double vfs[E2ETTS_MAX_STAGES + 1];  // fraction of the padded rows the limits of stage i leave (profile FLOP counts, tile choice without host lengths)
+  for (int i = 0; i <= E2ETTS_MAX_STAGES; ++i) vfs[i] = ragged_lens ? e->rag_frac_voc : 1.0;
   if (ragged_lens) {
     RET(ensure(e, e->actbuf, (size_t)(5 + c.voc_stages) * B * 4));
     int32_t* ab = ptr<int32_t>(e->actbuf) + 2 * B;
-    const int halo = vocoder_halo_frames(c);
+    long long halo[E2ETTS_MAX_STAGES + 1];
+    vocoder_stage_halo_rows(c, halo);
     if (ragged_lens_host) e->h_act.resize((size_t)(5 + c.voc_stages) * B, 0);
     long long rate = 1;
     for (int i = 0; i <= c.voc_stages; ++i) {
-      KCHK(e, launch_act_rows(ragged_lens, ab + (size_t)i * B, B, halo, (int)rate, (long long)T * rate, e->stream));
+      KCHK(e, launch_act_rows(ragged_lens, ab + (size_t)i * B, B, 0, (int)rate, (long long)T * rate, e->stream, halo[i]));
       act_stage[i] = ab + (size_t)i * B;
       if (ragged_lens_host) {  // act_rows_kernel's arithmetic on the host copy of its input
         int32_t* h = e->h_act.data() + (size_t)(2 + i) * B;
+        double sum = 0;
         for (int b = 0; b < B; ++b) {
           const long long m32 = std::min<long long>(ragged_lens_host[b], 0x7fffffffLL);
-          h[b] = (int32_t)std::min<long long>((m32 + halo) * rate, (long long)T * rate);
+          h[b] = (int32_t)std::min<long long>(m32 * rate + halo[i], (long long)T * rate);
+          sum += (double)std::max(h[b], 0);
         }
         act_stage_h[i] = h;
+        vfs[i] = sum / ((double)B * T * rate);
       }
       if (i < c.voc_stages) rate *= c.voc_up_rate[i];
     }
   }
-  const double vf = ragged_lens ? e->rag_frac_voc : 1.0;  // fraction of the padded rows the ragged limits leave (the same at every stage)
   // Small batches (the B = 1 latency path): the ResBlocks of a stage are independent until their sum (V/generator.py:44-48), and one
   // ResBlock's launches -- 384 tiles on 256 CUs at B = 1, chains of 40-70 us kernels -- leave CUs idle at every tail.  They run side by
   // side: ResBlock 0 on the engine's stream into S, ResBlock j > 0 on a side stream into a sum buffer of its own, joined by
@@ -1113,7 +1119,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     }
   } drain{e, conc ? nk - 1 : 0, false};
   ConvParams p;
-  p.B = B; p.T = T; p.act_rows = act_stage[0]; p.act_rows_host = act_stage_h[0]; p.act_frac = vf; p.in = mel_btc; setw(p, e->voc_pre); p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
+  p.B = B; p.T = T; p.act_rows = act_stage[0]; p.act_rows_host = act_stage_h[0]; p.act_frac = vfs[0]; p.in = mel_btc; setw(p, e->voc_pre); p.out = S; p.Cin = c.n_mel; p.Cout = c.voc_init_ch;
   p.KW = 7; p.pad = 3;
   RET(conv(e, p));
   long long n = T;
@@ -1124,7 +1130,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     // leaky_relu(0.1) -> ConvTranspose1d(k = 2s, stride s, pad s/2)  (V/generator.py:40-41) as a 3-tap convolution
     // with s * co output channels: row q of the [n, s*co] result IS rows q*s .. q*s+s-1 of the [n*s, co] signal.
     p = ConvParams();
-    p.B = B; p.T = (int)n; p.act_rows = act_stage[i]; p.act_rows_host = act_stage_h[i]; p.act_frac = vf; p.in = S; setw(p, e->voc_up[i]); p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
+    p.B = B; p.T = (int)n; p.act_rows = act_stage[i]; p.act_rows_host = act_stage_h[i]; p.act_frac = vfs[i]; p.in = S; setw(p, e->voc_up[i]); p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
     p.KW = 3; p.pad = 1; p.in_slope = 0.1f;
     p.zero_tap_split = s * co / 2;  // phases < s/2 never use tap 2, the others never tap 0 (packer.polyphase_upsampler)
     RET(conv(e, p, 2.0 / 3.0));
@@ -1165,7 +1171,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         ChainParams q;
         q.x = XU; q.wfrag = e->rb_pair_frag[idx][0]; q.out = S;
         for (int m = 0; m < 3; ++m) { q.b1[m] = e->rb_c1[idx][m].b; q.b2[m] = e->rb_c2[idx][m].b; q.dil[m] = c.voc_rb_dil[j][m]; }
-        q.act_rows = act_stage[i + 1]; q.act_rows_host = act_stage_h[i + 1]; q.act_frac = vf;
+        q.act_rows = act_stage[i + 1]; q.act_rows_host = act_stage_h[i + 1]; q.act_frac = vfs[i + 1];
         q.B = B; q.T = (int)n; q.C = co; q.KW = k;
         q.x_bs = q.out_bs = (long long)n * co;
         q.slope = 0.1f; q.mode = e->voc_precision;
@@ -1182,7 +1188,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         PairParams q;
         q.x = cur; q.wfrag = f32 ? e->rb_pair_frag32[idx][m] : e->rb_pair_frag[idx][m]; q.b1 = e->rb_c1[idx][m].b; q.b2 = e->rb_c2[idx][m].b;
         q.out = last ? S : (cur == CUR ? T1 : CUR);
-        q.act_rows = act_stage[i + 1]; q.act_rows_host = act_stage_h[i + 1]; q.act_frac = vf;
+        q.act_rows = act_stage[i + 1]; q.act_rows_host = act_stage_h[i + 1]; q.act_frac = vfs[i + 1];
         q.B = B; q.T = (int)n; q.C = co; q.KW = k; q.dil = c.voc_rb_dil[j][m];
         q.x_bs = q.out_bs = (long long)n * co;
         q.slope = 0.1f; q.mode = e->voc_precision;
@@ -1204,7 +1210,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         // ResBlock2 (V/layers.py:59-63): x = c(lrelu(x)) + x per dilation; the last one adds into the stage sum
         const bool last = m == c.voc_n_dil - 1;
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vf; p.in = cur; setw(p, e->rb_c1[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vfs[i + 1]; p.in = cur; setw(p, e->rb_c1[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = c.voc_rb_dil[j][m]; p.pad = (k * p.dil - p.dil) / 2; p.in_slope = 0.1f;
         if (last) {
           p.out = S;
@@ -1220,14 +1226,14 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         const int d = c.voc_rb_dil[j][m];
         // xt = c1(lrelu(x)); the lrelu that feeds c2 is applied here, in c1's epilogue (V/layers.py:35-38)
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vf; p.in = cur; setw(p, e->rb_c1[idx][m]); p.out = T1; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vfs[i + 1]; p.in = cur; setw(p, e->rb_c1[idx][m]); p.out = T1; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = d; p.pad = (k * d - d) / 2; p.in_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f;
         RET(conv(e, p));
         // x = c2(xt) + x (:38-39); the last pair adds into the stage sum, and the last ResBlock divides by num_kernels
         // (V/generator.py:44-48)
         const bool last = m == c.voc_n_dil - 1;
         p = ConvParams();
-        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vf; p.in = T1; setw(p, e->rb_c2[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
+        p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vfs[i + 1]; p.in = T1; setw(p, e->rb_c2[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = 1; p.pad = (k - 1) / 2;
         if (last) {
           p.out = S;
@@ -1276,7 +1282,8 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     e->istft_F = F;
   } else {
     ProfScope ps(e, "conv_post", 2.0 * B * (double)n * 7 * ch, (double)B * n * (ch * 4.0 + 6.0));
-    KCHK(e, launch_conv_post(S, e->voc_post.w, e->voc_post.b, ptr<float>(e->wav), ptr<int16_t>(e->pcm), B, n, (int)ch, 7, e->stream));
+    KCHK(e, launch_conv_post(S, e->voc_post.w, e->voc_post.b, ptr<float>(e->wav), ptr<int16_t>(e->pcm), B, n, (int)ch, 7, e->stream,
+                             act_stage[c.voc_stages], act_stage_h[c.voc_stages]));
   }
   (void)want_wav; (void)want_pcm;
   e->voc_B = B; e->voc_T = T;
@@ -1723,6 +1730,20 @@ int e2etts_set_ragged(e2etts_engine* e, int enable) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
   e->ragged = enable != 0;
+  return E2ETTS_OK;
+}
+
+int e2etts_debug_poison_workspace(e2etts_engine* e) {
+  if (!e) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  DevBuf* bufs[] = {&e->xa, &e->xb, &e->xs, &e->xp, &e->tmp, &e->qkv, &e->att, &e->hid, &e->p1, &e->p2, &e->attws, &e->dx, &e->dxb, &e->mel,
+                    &e->melpost, &e->pn1, &e->pn2, &e->melin, &e->v0, &e->v1, &e->v2, &e->v3, &e->wav, &e->pcm, &e->istft_q, &e->istft_ri, &e->istft_sp};
+  for (DevBuf* b : bufs)
+    if (b->p) HIPCHK(e, hipMemsetAsync(b->p, 0x4B, b->cap, e->stream));
+  for (auto& row : e->vside)
+    for (DevBuf& b : row)
+      if (b.p) HIPCHK(e, hipMemsetAsync(b.p, 0x4B, b.cap, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
   return E2ETTS_OK;
 }
 

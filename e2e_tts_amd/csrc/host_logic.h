@@ -110,22 +110,34 @@ inline const char* config_check(const e2etts_config& c) {
   return nullptr;
 }
 
-// Frames of mel context one output frame depends on, each side (conservative bound from the layer geometry: conv_post 3
-// samples, per stage the widest ResBlock1 sum_m ((k-1)/2 d_m + (k-1)/2), each upsampler +-2 input positions, conv_pre 3 frames).
-inline int vocoder_halo_frames(const e2etts_config& c) {
-  // HiFi-GAN tail: conv_post reaches 3 samples.  iSTFTNet tail: conv_post 3 frames + the reflection pad's shift of 1 + the inverse
-  // STFT's overlap (a sample is the sum of n_fft / hop frames: n_fft / (2 hop) to either side), all at the trunk's output rate
-  double r = c.voc_istft_nfft ? 4.0 + (double)c.voc_istft_nfft / (2.0 * c.voc_istft_hop) : 3.0;
-  for (int i = c.voc_stages - 1; i >= 0; --i) {
-    int worst = 0;
+// Rows past the last valid one (mel_len * rate_i) that the layers of vocoder stage i have to compute so that every valid sample sees
+// exactly the inputs the padded computation gives it: out[i], i = 0 .. voc_stages (i = 0: conv_pre's output, rate 1; i >= 1: the
+// upsampler output and the ResBlocks of stage i, rate = product of the first i upsampling factors).  Conservative bound from the
+// layer geometry, back to front: the tail reads `tail` rows of the trunk's output past a sample (conv_post: 3; iSTFTNet: conv_post 3
+// frames + the reflection pad's shift of 1 + the inverse STFT's overlap -- a sample is the sum of n_fft / hop frames, n_fft / (2 hop) to
+// either side); every layer of a stage computes the rows its output needs plus the widest ResBlock's reach
+// sum_m ((k-1)/2 d_m + (k-1)/2) (one limit per stage covers the intermediate layers too); an upsampler reads +-2 input positions.
+inline void vocoder_stage_halo_rows(const e2etts_config& c, long long out[E2ETTS_MAX_STAGES + 1]) {
+  long long need = c.voc_istft_nfft ? 4 + (c.voc_istft_nfft + 2 * c.voc_istft_hop - 1) / (2 * c.voc_istft_hop) : 3;
+  for (int i = c.voc_stages; i >= 1; --i) {
+    long long worst = 0;
     for (int j = 0; j < c.voc_n_kernels; ++j) {
-      int sum = 0;
-      for (int m = 0; m < c.voc_n_dil; ++m) sum += (c.voc_rb_kernel[j] - 1) / 2 * (c.voc_rb_dil[j][m] + 1);
+      long long sum = 0;
+      for (int m = 0; m < c.voc_n_dil; ++m) sum += (long long)(c.voc_rb_kernel[j] - 1) / 2 * (c.voc_rb_dil[j][m] + 1);
       worst = sum > worst ? sum : worst;
     }
-    r = (r + worst) / c.voc_up_rate[i] + 2.0;
+    out[i] = need + worst;
+    const long long r = c.voc_up_rate[i - 1];
+    need = (out[i] + r - 1) / r + 2;
   }
-  return (int)std::ceil(r + 3.0);
+  out[0] = need;
+}
+
+// Frames of mel context one output frame depends on, each side: conv_pre's output limit plus its own 3 frames.
+inline int vocoder_halo_frames(const e2etts_config& c) {
+  long long h[E2ETTS_MAX_STAGES + 1];
+  vocoder_stage_halo_rows(c, h);
+  return (int)std::min<long long>(h[0] + 3, 1 << 24);
 }
 
 // conv_gemm tile choice for Cout > 64 (rows = T per utterance).  few: so few tiles (small batches, the B = 1 latency path, the encoder)

@@ -121,8 +121,8 @@ const char* launch_variance_embed(float* x, float* pitch_pred /*[B,L,2], scaled 
 // length regulator fused with the decoder position add: y[b, t, :] = (t < mel_len[b] ? x[b, ph(t), :] : 0) + pos[t, :]
 const char* launch_length_regulate(const float* x, const int32_t* cum, const int32_t* mel_lens, const float* pos,
                                    float* y, int B, int L, int T, int H, hipStream_t s);
-// out[b] = min(cap, (lens[b] + add) * mul): rows a layer has to compute for utterance b in ragged mode
-const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s);
+// out[b] = min(cap, (lens[b] + add) * mul + add_rows): rows a layer has to compute for utterance b in ragged mode
+const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s, long long add_rows = 0);
 // S = (S + Sj) [+ Sk] [/ div] over n floats (n % 4 == 0): joins the sums of ResBlocks run on side streams
 const char* launch_accum_div(float* S, const float* Sj, long long n, float div, hipStream_t s, const float* Sk = nullptr);
 // [B, C, T] -> [B, T, C]
@@ -208,7 +208,8 @@ const char* launch_wsola(const int16_t* x, long long n_in, int16_t* out, long lo
 
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s);
 // wav = tanh(conv7(lrelu_0.01(x))) with Cout = 1; pcm = (int16)(int32)(wav * 32768)
+// act_rows / act_rows_host (optional, device / host copies of the same B values): only samples < act_rows[b] are written (ragged batches)
 const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,
-                             long long N, int C, int KW, hipStream_t s);
+                             long long N, int C, int KW, hipStream_t s, const int32_t* act_rows = nullptr, const int32_t* act_rows_host = nullptr);
 
 }  // namespace e2etts

@@ -3,6 +3,8 @@
 // vocoder's 1-channel output convolution.  fp32 throughout; float4 (16 B / lane) global accesses.
 #include <math.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace e2etts {
@@ -266,10 +268,10 @@ __global__ __launch_bounds__(128) void length_regulate_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------- ragged-batch row limits
-__global__ void act_rows_kernel(const int32_t* __restrict__ lens, int32_t* __restrict__ out, int B, int add, int mul, long long cap) {
+__global__ void act_rows_kernel(const int32_t* __restrict__ lens, int32_t* __restrict__ out, int B, int add, int mul, long long cap, long long add_rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) {
-    const long long v = ((long long)lens[i] + add) * mul;
+    const long long v = ((long long)lens[i] + add) * mul + add_rows;
     out[i] = (int32_t)(v < cap ? v : cap);
   }
 }
@@ -595,15 +597,23 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 template <int TPB>
 __global__ __launch_bounds__(TPB) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ wav,
-                                                        int16_t* __restrict__ pcm, long long N, int C, int KW) {
+                                                        int16_t* __restrict__ pcm, long long N, int C, int KW,
+                                                        const int32_t* __restrict__ act_rows, const RowMap rm) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ldx = C + 4;
   const int pad = (KW - 1) / 2;
   const int rows = TPB + KW - 1;
   float* xs = sm;
   float* ws = sm + rows * ldx;
-  const int b = blockIdx.y;
-  const long long t0 = (long long)blockIdx.x * TPB;
+  int b, blk;   // ragged batch, lengths known on the host: a compact 1-D grid of the blocks that have samples to write (kernels.h: RowMap)
+  if (rm.n > 0) {
+    if (!rowmap_find(rm, (int)blockIdx.x, b, blk)) return;
+  } else {
+    b = blockIdx.y;
+    blk = blockIdx.x;
+  }
+  const long long t0 = (long long)blk * TPB;
+  if (act_rows && t0 >= act_rows[b]) return;   // samples nobody needs (uniform for the block, before the barrier)
   const float* xb = x + (long long)b * N * C;
   const int c4n = C / 4;
   for (int i = threadIdx.x; i < rows * c4n; i += TPB) {
@@ -738,9 +748,9 @@ const char* launch_accum_div(float* S, const float* Sj, long long n, float div, 
   return hipGetLastError() == hipSuccess ? nullptr : "accum_div: launch failed";
 }
 
-const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s) {
+const char* launch_act_rows(const int32_t* lens, int32_t* out, int B, int add, int mul, long long cap, hipStream_t s, long long add_rows) {
   if (!lens || !out || B <= 0) return "act_rows: bad arguments";
-  hipLaunchKernelGGL(act_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lens, out, B, add, mul, cap);
+  hipLaunchKernelGGL(act_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lens, out, B, add, mul, cap, add_rows);
   return CHECK_LAUNCH("act_rows");
 }
 
@@ -858,14 +868,26 @@ const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, 
 }
 
 const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,
-                             long long N, int C, int KW, hipStream_t s) {
+                             long long N, int C, int KW, hipStream_t s, const int32_t* act_rows, const int32_t* act_rows_host) {
   if (!x || !w || !bias) return "conv_post: null pointer";
   if (C % 4 || C <= 0 || C > 128 || KW <= 0 || KW > 15 || !(KW & 1)) return "conv_post: bad dims";
   constexpr int TPB = 256;
   const size_t lds = ((size_t)(TPB + KW - 1) * (C + 4) + (size_t)KW * C) * sizeof(float);
   if (lds > 64 * 1024) return "conv_post: LDS tile exceeds 64 KiB";
   dim3 grid((unsigned)((N + TPB - 1) / TPB), B);
-  hipLaunchKernelGGL(conv_post_kernel<TPB>, grid, dim3(TPB), lds, s, x, w, bias, wav, pcm, N, C, KW);
+  RowMap rm;
+  if (act_rows && act_rows_host && B <= ROWMAP_MAX) {
+    rm.n = B;
+    rm.identity();
+    rm.cum[0] = 0;
+    for (int b = 0; b < B; ++b) {
+      const long long r = std::min<long long>(std::max(act_rows_host[b], 0), N);
+      rm.cum[b + 1] = rm.cum[b] + (int)((r + TPB - 1) / TPB);
+    }
+    if (rm.cum[B] == 0) return nullptr;
+    grid = dim3((unsigned)rm.cum[B]);
+  }
+  hipLaunchKernelGGL(conv_post_kernel<TPB>, grid, dim3(TPB), lds, s, x, w, bias, wav, pcm, N, C, KW, act_rows, rm);
   return CHECK_LAUNCH("conv_post");
 }
 

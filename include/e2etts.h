@@ -190,7 +190,7 @@ int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decod
 
 /* Ragged batches (default on).  e2etts_synthesize hands back, per utterance, only mel_lens[b] * hop valid samples; with
  * ragged != 0 it therefore skips, layer by layer, the rows of shorter utterances that no valid sample depends on (rows past
- * mel_len + receptive-field halo), instead of computing the whole padded batch as the reference does.  Valid samples are
+ * mel_len + the receptive field of the layers still to come, stage by stage), instead of computing the whole padded batch as the reference does.  Valid samples are
  * bit-identical either way; what lies beyond them in the padded PCM rows is then unspecified.  e2etts_acoustic /
  * e2etts_vocoder always compute the full padded tensors (their padded rows match the reference's).
  * The frame level (decoder, postnet, vocoder) is skipped from the mel lengths the engine computes itself; the phoneme level (encoder,
@@ -198,6 +198,11 @@ int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decod
  * memory the phoneme level computes the padded batch -- same results).  Batches of up to 64 utterances launch grids without idle
  * workgroups; larger ones still skip the rows but keep the padded grid. */
 int e2etts_set_ragged(e2etts_engine* engine, int enable);
+
+/* Test hook for ragged mode: overwrite the activation workspaces (not the weights, not the index buffers) with a large finite pattern
+ * (every byte 0x4B: 1.3e7 as fp32), so that a test can show that no valid sample of the next call depends on what an earlier call left
+ * in the rows that ragged compute skips.  No effect on results by construction; nothing in the product path calls it. */
+int e2etts_debug_poison_workspace(e2etts_engine* engine);
 
 /* Fused ResBlocks (bf16 modes).  level 1: each (conv k, dilation d -> leaky ReLU -> conv k -> + x) pair of HiFi-GAN's ResBlock1
  * (reference V/layers.py:33-40) at 32 / 64 / 128 / 256 channels runs as ONE kernel whose intermediate stays in LDS.  level 2

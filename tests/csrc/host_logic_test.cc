@@ -3,7 +3,7 @@
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all
 // and fed valid, truncated and corrupt inputs; any out-of-bounds read or integer overflow aborts the process (non-zero exit).
 //   host_logic_test blob <file>         -> "OK <n_tensors> <sum of numel>" | "ERR <message>"
-//   host_logic_test config <file>       -> "OK halo=<frames>" | "ERR <message>"     (file = raw e2etts_config bytes)
+//   host_logic_test config <file>       -> "OK halo=<frames> stage_rows=<r0,r1,..>" | "ERR <message>"     (file = raw e2etts_config bytes)
 //   host_logic_test tiles B T Cout      -> "few=<0|1> half=<0|1>"
 #include <cstdio>
 #include <cstdlib>
@@ -56,7 +56,11 @@ int main(int argc, char** argv) {
     e2etts_config c;
     memcpy(&c, buf.data(), sizeof c);
     if (const char* m = config_check(c)) { printf("ERR %s\n", m); return 0; }
-    printf("OK halo=%d\n", vocoder_halo_frames(c));
+    long long h[E2ETTS_MAX_STAGES + 1];
+    vocoder_stage_halo_rows(c, h);
+    printf("OK halo=%d stage_rows=", vocoder_halo_frames(c));
+    for (int i = 0; i <= c.voc_stages; ++i) printf(i ? ",%lld" : "%lld", h[i]);
+    printf("\n");
     return 0;
   }
   if (argc >= 5 && !strcmp(argv[1], "tiles")) {

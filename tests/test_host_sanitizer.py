@@ -108,7 +108,9 @@ def test_config_validation_and_halo(harness, tiny_blob, tmp_path):
     assert run(harness, "config", f).startswith("OK halo=")
     d = cfgmod.dims_from_config(cfgmod.default_config(), cfgmod.DEFAULT_STATS, n_speakers=4).to_c()
     f.write_bytes(bytes(ctypes.string_at(ctypes.addressof(d), ctypes.sizeof(d))))
-    assert run(harness, "config", f) == "OK halo=15"   # HiFi-GAN V1 (include/e2etts.h: streaming vocoder)
+    # HiFi-GAN V1 (include/e2etts.h: streaming vocoder; ragged limits per stage: conv_post 3 + ResBlock reach 60 = 63 rows at the
+    # output rate, then (rows / rate + 2) + 60 stage by stage towards the mel)
+    assert run(harness, "config", f) == "OK halo=15 stage_rows=12,76,109,94,63"
     # every int32 field forced to hostile values: rejected or accepted, never a sanitizer report (shift / overflow / index)
     n_fields = len(raw) // 4
     for val in (0, -1, 0x7FFFFFFF, -0x80000000, 1 << 20, 3):

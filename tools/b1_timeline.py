@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""One step of a rocprofv3 kernel trace as a timeline: start [us since the step's first kernel], duration, stream, grid, kernel.
+
+    python3 tools/b1_timeline.py <kernel_trace.csv> [first kernel of a step = embed_kernel]
+
+Takes the LAST complete step in the trace (from one `embed_kernel` to the next).  A tuning aid for the B = 1 latency path, where the order
+and overlap of ~190 short launches matter more than any one kernel's rate."""
+import csv
+import re
+import sys
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    first = sys.argv[2] if len(sys.argv) > 2 else "embed_kernel"
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    def short(n):
+        n = re.sub(r"^(void )?e2etts::\(anonymous namespace\)::", "", n)
+        return re.sub(r"\(.*$", "", n)
+    starts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == first]
+    if len(starts) < 2:
+        raise SystemExit("need two steps in the trace")
+    a, b = starts[-2], starts[-1]
+    t0 = int(rows[a]["Start_Timestamp"])
+    streams = {}
+    print("# start_us  dur_us  stream  threads  kernel")
+    for r in rows[a:b]:
+        s = streams.setdefault(r.get("Stream_Id", r.get("Queue_Id", "0")), len(streams) + 1)
+        name = short(r["Kernel_Name"])
+        threads = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f}  s{s}  {threads:8d}  {name}")
+    print(f"# step: {(int(rows[b]['Start_Timestamp']) - t0) / 1e3:.1f} us between first kernels")
+
+
+if __name__ == "__main__":
+    main()

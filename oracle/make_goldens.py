@@ -558,6 +558,9 @@ def main():
         "c2_latency": lambda: case_model(models, "c2_latency", full, "fixed", [128], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
         "c3_mixed": lambda: case_model(models, "c3_mixed", full, "fixed", c3_lengths(), 1, (1.0, 1.0, 1.0), 2, 1e-4, "digest", max_tries=60),
         "bench_b32": lambda: case_bench_b32(models),   # after c2_latency: its row 0 is that fixture's utterance
+        # one long utterance next to a short one: T = 3 072 frames = 12 key segments of the attention kernels (c3_mixed has 5), a position
+        # table regenerated for 3 x max_seq_len, ragged limits that leave 93 % of the second row untouched
+        "full_long": lambda: case_model(models, "full_long", full, "fixed", [512, 37], 2, (1.0, 1.0, 1.0), 900, 1e-4, "digest", max_tries=20),
     }
     if not args.skip_large:
         jobs.update(large)

@@ -108,16 +108,18 @@ def test_default_model(name):
             assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < WAV_L1 * n, prec
 
 
-def test_c3_mixed_batch32():
-    """BASELINE config 3: B = 32 mixed lengths 40..200 (T = 1200 > max_seq_len: regenerated position table)."""
-    g = load_golden("c3_mixed")
-    cfg, eng = engine_for(g, "c3_mixed")
+@pytest.mark.parametrize("name", ["c3_mixed", "full_long"])
+def test_c3_mixed_batch32(name):
+    """c3_mixed -- BASELINE config 3: B = 32 mixed lengths 40..200 (T = 1200 > max_seq_len: regenerated position table).
+    full_long -- 512 phonemes next to 37: T = 3 072 frames, 12 key segments in the attention kernels, position table for 3 x max_seq_len."""
+    g = load_golden(name)
+    cfg, eng = engine_for(g, name)
     sel = g["sel"]
     fs = int(g["mel_frame_stride"])
     for prec in ("fp32", "bf16x3"):   # ends on the default, whose resident mel_post feeds the vocoder checks below
         r, mel, mel_post = run_acoustic(eng, g, prec)
         check_discrete(r, g)
-        print(f"c3_mixed {prec}: mel_post mean-L1 {mean_l1(mel_post[sel][:, ::fs], g['mel_post_sel']):.3e}")
+        print(f"{name} {prec}: mel_post mean-L1 {mean_l1(mel_post[sel][:, ::fs], g['mel_post_sel']):.3e}")
         assert mean_l1(mel_post[sel][:, ::fs], g["mel_post_sel"]) < MEL_L1, prec
         for b, n in enumerate(g["mel_lens"]):
             assert abs(np.abs(mel_post[b, :n].astype(np.float64)).sum() - g["mel_post_abs_sum"][b]) < MEL_L1 * n * 80, prec
@@ -127,7 +129,7 @@ def test_c3_mixed_batch32():
         eng.set_precision(prec)
         wav, _ = eng.vocoder(None, r["B"], r["T"])
         err = mean_l1(wav[sel][:, ::ws], g["wav_strided_sel"])
-        print(f"c3_mixed {prec}: wav mean-L1 {err:.3e}")
+        print(f"{name} {prec}: wav mean-L1 {err:.3e}")
         assert err < WAV_L1, prec
         for b, n in enumerate(g["mel_lens"] * hop):
             assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < WAV_L1 * n, prec
@@ -555,7 +557,7 @@ def test_conformer_rejects_sequences_beyond_the_position_table():
         eng.acoustic(rng.integers(4, 131, size=(1, 100)).astype(np.int64), np.array([100], np.int64), np.array([0], np.int64))
 
 
-@pytest.mark.parametrize("name", ["tiny_b3", "tiny_ctl", "full_b3", "c3_mixed", "tiny_cf_b3"])
+@pytest.mark.parametrize("name", ["tiny_b3", "tiny_ctl", "full_b3", "c3_mixed", "full_long", "tiny_cf_b3"])
 def test_ragged_synthesize_is_bit_identical_on_valid_samples(name):
     """synthesize() with ragged compute (skip what no valid sample depends on) vs the full padded batch: same PCM on every
     valid sample, and within 1 LSB of the reference's waveform there."""

@@ -52,6 +52,24 @@ def test_acoustic_and_vocoder_match_reference(name):
             assert abs(np.abs(wav[b, :n].astype(np.float64)).sum() - g["wav_abs_sum"][b]) < 1e-5 * n
 
 
+def test_long_utterance_acoustic_oracle_matches_reference():
+    """full_long: one utterance of 512 phonemes (T = 3 072 frames, three times max_seq_len: regenerated position table) next to one of 37;
+    acoustic model only (the numpy vocoder would take minutes at this length; the fixture's waveform pins the GPU path)."""
+    g = load_golden("full_long")
+    cfg, ac_state, _ = states_for(g, "full_long")
+    ac = orc.AcousticOracle(ac_state, cfg, cfgmod.DEFAULT_STATS)
+    d, p, e = (float(x) for x in g["controls"])
+    (mel, mel_post, dur), mel_lens = ac.inference(np.array([int(g["speaker"])]), g["ids"], g["lens"], d, p, e)
+    np.testing.assert_array_equal(dur, g["dur"])
+    np.testing.assert_array_equal(mel_lens, g["mel_lens"])
+    np.testing.assert_array_equal(ac.trace["pitch_idx"], g["pitch_idx"])
+    np.testing.assert_array_equal(ac.trace["energy_idx"], g["energy_idx"])
+    fs = int(g["mel_frame_stride"])
+    assert mean_l1(mel_post[g["sel"]][:, ::fs], g["mel_post_sel"]) < 1e-5
+    for b, n in enumerate(g["mel_lens"]):
+        assert abs(np.abs(mel_post[b, :n].astype(np.float64)).sum() - g["mel_post_abs_sum"][b]) < 1e-5 * n * 80
+
+
 def test_vocoder_stages_match_reference():
     g = load_golden("voc_micro_tiny")
     cfg = cfgmod.tiny_config()

@@ -40,6 +40,34 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD / 1) void mfma_loop(const uint
   out[tid] = s;
 }
 
+// The same for the exact-fp32 path: nothing but v_mfma_f32_32x32x2_f32 (64 cycles each, 4096 FLOP), 16 independent-enough MFMAs per iteration.
+__global__ __launch_bounds__(256) void mfma_loop_f32(const float* __restrict__ in, float* __restrict__ out, int iters) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  float a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = in[(tid * 8 + i) & 0xffff];
+    b[i] = in[(tid * 8 + 4 + i) & 0xffff];
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[(i + j) & 3], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[tid] = s;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main() {
@@ -47,7 +75,7 @@ int main() {
   std::vector<unsigned> h(65536 * 4);
   uint4* din; float* dout;
   CK(hipMalloc(&din, h.size() * 4));
-  CK(hipMalloc(&dout, CUS * 8 * 256 * 4));
+  CK(hipMalloc(&dout, CUS * 12 * 256 * 4));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int zeros = 0; zeros < 2; ++zeros) {
@@ -72,6 +100,29 @@ int main() {
       const double cyc_per_simd = (double)iters * 16 * 32 * wps;     // 32 cycles per MFMA, wps waves share a SIMD
       printf("%s operands, %d wave(s) per SIMD: %.1f ms  %.0f TFLOP/s bf16 dense (= %.0f TFLOP/s of split-precision products)  implied clock %.2f GHz\n",
              zeros ? "zero  " : "random", wps, ms, flops / ms / 1e9, flops / ms / 1e9 / 3, cyc_per_simd / (ms * 1e6));
+    }
+  }
+  // exact fp32: operands small enough that 3.2 M accumulations stay finite
+  std::vector<float> hf(65536 * 4);
+  for (int zeros = 0; zeros < 2; ++zeros) {
+    srand(2);
+    for (auto& w : hf) w = zeros ? 0.f : (float)(rand() % 2001 - 1000) / 4.0e6f;
+    CK(hipMemcpy(din, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+    const int it32 = 50000;
+    for (int wps = 1; wps <= 3; ++wps) {
+      const int blocks = CUS * wps;
+      hipLaunchKernelGGL(mfma_loop_f32, dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const float*>(din), dout, 1000);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(mfma_loop_f32, dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const float*>(din), dout, it32);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double mfmas = (double)blocks * 4 * it32 * 16;
+      const double flops = mfmas * 2.0 * 32 * 32 * 2;
+      const double cyc_per_simd = (double)it32 * 16 * 64 * wps;      // 64 cycles per MFMA
+      printf("fp32 %s operands, %d wave(s) per SIMD: %.1f ms  %.1f TFLOP/s fp32 (v_mfma_f32_32x32x2_f32)  implied clock %.2f GHz\n",
+             zeros ? "zero  " : "random", wps, ms, flops / ms / 1e9, cyc_per_simd / (ms * 1e6));
     }
   }
   return 0;

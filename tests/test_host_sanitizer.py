@@ -152,3 +152,73 @@ def test_ragged_counts(harness):
     assert out.startswith("t128=") and out.endswith("few=0 half=1"), out
     assert run(harness, "tiles", 32, 1200, 1024) == "few=0 half=0"
     assert run(harness, "ragged", 0x7FFFFFFF, 0x7FFFFFFF, *([0x7FFFFFFF] * 64)).startswith("t128=")
+
+
+def _exact_stage_rows(rates, kernels, dils, resblock=1, tail=3):
+    """Rows past the last valid one that each vocoder stage must hold CORRECT values for, from the layer index maps alone
+    (V/generator.py:37-53, V/layers.py:33-40,59-62): conv_post reads +-3 samples; a ResBlock1 pair (conv k dilation d, conv k) reaches
+    (k - 1) / 2 * (d + 1) rows, a ResBlock2 convolution (k - 1) / 2 * d; ConvTranspose1d(k = 2 r, stride r, padding r / 2) output t
+    reads inputs up to floor((t + r / 2) / r)."""
+    need = tail
+    rows = [0] * (len(rates) + 1)
+    for i in range(len(rates), 0, -1):
+        reach = max(sum((k - 1) // 2 * (d + (1 if resblock == 1 else 0)) for d in dl) for k, dl in zip(kernels, dils))
+        rows[i] = need + reach
+        r = rates[i - 1]
+        need = (rows[i] - 1 + r // 2) // r + 1
+    rows[0] = need
+    return rows
+
+
+def test_stage_limits_cover_the_exact_receptive_field(harness, tmp_path):
+    """host_logic.h: vocoder_stage_halo_rows (the ragged limits of every vocoder stage) against an independent derivation from the layer
+    geometry, for every generator the fixtures use: never less than the exact reach, never more than a few rows above it."""
+    cases = []
+    for make in (cfgmod.tiny_config, cfgmod.default_config):
+        cfg = make()
+        cases.append((cfg, "hifigan"))
+    c48 = cfgmod.default_config()   # BASELINE config 5's generator (tests/golden/hifigan_48k.npz)
+    c48["models"]["hifigan"].update(upsample_rates=[8, 8, 4, 2], upsample_kernel_sizes=[16, 16, 8, 4])
+    c48["audio"]["stft"]["hop_length"] = 512
+    cases.append((c48, "hifigan"))
+    f = tmp_path / "cfg.bin"
+    for cfg, voc in cases:
+        hg = cfg["models"][voc]
+        d = cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, n_speakers=4, vocoder=voc).to_c()
+        f.write_bytes(bytes(ctypes.string_at(ctypes.addressof(d), ctypes.sizeof(d))))
+        out = run(harness, "config", f)
+        assert out.startswith("OK halo="), out
+        got = [int(x) for x in out.split("stage_rows=")[1].split(",")]
+        halo = int(out.split("halo=")[1].split()[0])
+        want = _exact_stage_rows(hg["upsample_rates"], hg["resblock_kernel_sizes"], hg["resblock_dilation_sizes"], int(hg.get("resblock", 1)))
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert w <= g <= w + 4, (got, want)
+        assert halo == got[0] + 3   # conv_pre's own reach
+
+
+def test_halo_frames_hold_numerically_on_the_oracle_vocoder(harness, tmp_path):
+    """The frame halo the engine uses (streaming context, ragged limits) against the numpy HifiGan restatement: changing the mel from frame
+    t0 + halo on must leave every sample of the first t0 frames untouched bit for bit, and one frame earlier than the exact reach must not
+    (so the bound is tight to within its stated slack, not vacuous)."""
+    from e2e_tts_amd import synth_weights as sw
+    from oracle import ref_numpy as orc
+    cfg = cfgmod.tiny_config()
+    d = cfgmod.dims_from_config(cfg, cfgmod.DEFAULT_STATS, n_speakers=4).to_c()
+    f = tmp_path / "cfg.bin"
+    f.write_bytes(bytes(ctypes.string_at(ctypes.addressof(d), ctypes.sizeof(d))))
+    out = run(harness, "config", f)
+    halo = int(out.split("halo=")[1].split()[0])
+    voc = orc.VocoderOracle(sw.make_vocoder_state(cfg, seed=5), cfg)
+    hop = cfg["audio"]["stft"]["hop_length"]
+    n_mel = cfg["audio"]["mel"]["channels"]
+    rng = np.random.Generator(np.random.PCG64(11))
+    t0, T = 9, 9 + halo + 6
+    mel = rng.standard_normal((1, n_mel, T)).astype(np.float32)
+    base = voc.forward(mel)[0, 0]
+    far = mel.copy()
+    far[:, :, t0 + halo:] += 3.0
+    np.testing.assert_array_equal(voc.forward(far)[0, 0][: t0 * hop], base[: t0 * hop])
+    near = mel.copy()
+    near[:, :, t0 + 2:] += 3.0   # two frames past the end: well inside the receptive field
+    assert not np.array_equal(voc.forward(near)[0, 0][: t0 * hop], base[: t0 * hop])

@@ -50,7 +50,9 @@ def kernel_class(name: str):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
-    title = sys.argv[4] if len(sys.argv) > 4 and sys.argv[3] == "--title" else "PMC summary"
+    title = sys.argv[sys.argv.index("--title") + 1] if "--title" in sys.argv else "PMC summary"
+    # --args "...": the bench.py arguments of the passes when they are not the headline's (one workload, one arithmetic mode)
+    extra = sys.argv[sys.argv.index("--args") + 1] if "--args" in sys.argv else None
     # --name FILE.md: write the table under that name and leave profiles/pmc_traffic.json (bench.py's `roofline.traffic` source, which
     # belongs to the headline workload) alone -- for side workloads such as `bench.py --blocks conformer`
     name = sys.argv[sys.argv.index("--name") + 1] if "--name" in sys.argv else None
@@ -77,9 +79,11 @@ def main():
         sys.exit(f"no counter_collection.csv with known kernels under {src}")
     os.makedirs(dst, exist_ok=True)
     traffic = {}
-    lines = [f"# {title}", "",
-             "Separate `rocprofv3 --pmc` passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` -- once in the default",
-             "exact-fp32 arithmetic (classes conv_gemm_*) and once with `--precision bf16x3` (classes conv_x3_*, resblock_*) -- counters only, no",
+    what = (f"Separate `rocprofv3 --pmc` passes of `python3 bench.py {extra} --steps 2 --warmup 1 --no-cpu-baseline --no-extras` -- counters only, no"
+            if extra else
+            "Separate `rocprofv3 --pmc` passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` -- once in the default\n"
+            "exact-fp32 arithmetic (classes conv_gemm_*) and once with `--precision bf16x3` (classes conv_x3_*, resblock_*) -- counters only, no")
+    lines = [f"# {title}", "", what,
              "trace domains, summarised by tools/pmc_summary.py.  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs):",
              "GRBM_GUI_ACTIVE is summed over the 8 XCDs, a bf16 MFMA counts its own 32 cycles, so 1.00 = the dense peak AT THE CLOCK HELD.",
              "clock = GRBM_GUI_ACTIVE / 8 / kernel time.  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B reads as 64 B).", "",

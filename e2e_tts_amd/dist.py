@@ -109,6 +109,25 @@ def gather_pcm(local: List[Tuple[int, np.ndarray]], dst: int = 0, device=None, s
     return merged
 
 
+def _agree_or_raise(failure: Optional[BaseException], device=None) -> None:
+    """Every rank learns whether ANY rank failed before the first collective of the gather (one MIN all-reduce of a flag), so that a rank
+    whose engine raised makes all ranks raise instead of leaving the others waiting in a collective it never enters."""
+    import torch
+    import torch.distributed as dist
+    world, rank = _world_rank()
+    if world == 1:
+        if failure is not None:
+            raise failure
+        return
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if failure is not None:
+        raise RuntimeError(f"synthesize_sharded: rank {rank} failed: {failure!r}") from failure
+    if int(ok.item()) == 0:
+        raise RuntimeError(f"synthesize_sharded: another rank failed (rank {rank} was fine); nothing gathered")
+
+
 def synthesize_sharded(engine, id_lists: Sequence[Sequence[int]], speaker: int = 0, batch_size: int = 32, hop_length: Optional[int] = None,
                        controls: Tuple[float, float, float] = (1.0, 1.0, 1.0), dst: int = 0, device=None, stats: Optional[Dict] = None):
     """BASELINE config 4 end to end (256 utterances over 8 GPUs): every rank holds the SAME list of phoneme-id lists, takes its shard
@@ -116,6 +135,7 @@ def synthesize_sharded(engine, id_lists: Sequence[Sequence[int]], speaker: int =
     reference API/utils.py:84) with its own engine, and rank `dst` receives the int16 PCM of every utterance in input order
     (None elsewhere).  No collective on the data path: the only communication is the final gather of the PCM (`gather_pcm`; `device`
     as there).  Without an initialised process group it is the one-GPU form of the same loop (reference API/utils.py:130-151).
+    A rank whose engine raises makes EVERY rank raise (the ranks agree on one flag before the gather), never a hang.
 
     `engine` is an `e2e_tts_amd._lib.Engine` (anything with `.synthesize(ids, lens, speaker, d, p, e) -> (pcm, mel_lens, T)` and
     `.dims.hop_length`).  `stats` (optional dict) receives on `dst`: `samples_per_rank`, `balance_max_over_mean` (largest rank's valid
@@ -129,16 +149,21 @@ def synthesize_sharded(engine, id_lists: Sequence[Sequence[int]], speaker: int =
     spk = np.array([int(speaker)], np.int64)
     local: List[Tuple[int, np.ndarray]] = []
     n_batches = 0
-    for start in range(0, len(mine), batch_size):
-        idx = mine[start:start + batch_size]
-        lens = np.array([lens_all[i] for i in idx], np.int64)
-        ids = np.zeros((len(idx), int(lens.max())), np.int64)
-        for b, i in enumerate(idx):
-            ids[b, :lens[b]] = np.asarray(id_lists[i], np.int64)
-        pcm, mel_lens, _ = engine.synthesize(ids, lens, spk, *controls)
-        n_batches += 1
-        for b, i in enumerate(idx):
-            local.append((i, np.array(pcm[b, :int(mel_lens[b]) * hop], copy=True)))
+    failure: Optional[BaseException] = None
+    try:
+        for start in range(0, len(mine), batch_size):
+            idx = mine[start:start + batch_size]
+            lens = np.array([lens_all[i] for i in idx], np.int64)
+            ids = np.zeros((len(idx), int(lens.max())), np.int64)
+            for b, i in enumerate(idx):
+                ids[b, :lens[b]] = np.asarray(id_lists[i], np.int64)
+            pcm, mel_lens, _ = engine.synthesize(ids, lens, spk, *controls)
+            n_batches += 1
+            for b, i in enumerate(idx):
+                local.append((i, np.array(pcm[b, :int(mel_lens[b]) * hop], copy=True)))
+    except Exception as ex:   # noqa: BLE001 -- re-raised below, on every rank
+        failure = ex
+    _agree_or_raise(failure, device)
     if stats is not None:
         stats["batches"] = n_batches
     merged = gather_pcm(local, dst=dst, device=device, stats=stats)

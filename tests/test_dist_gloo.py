@@ -120,6 +120,35 @@ def test_synthesize_sharded_world2(tmp_path):
     assert (tmp_path / "sharded_ok.npy").exists()
 
 
+def _failing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lists = [[k + 1] * (k + 2) for k in range(9)]
+    eng = _StubEngine()
+    if rank == 1:
+        def boom(*a, **k):
+            raise ValueError("engine error on one rank")
+        eng.synthesize = boom
+    try:
+        edist.synthesize_sharded(eng, lists, speaker=1, batch_size=4)
+    except RuntimeError as ex:
+        with open(os.path.join(out_dir, f"raised{rank}.txt"), "w") as fh:
+            fh.write(str(ex))
+    dist.barrier()   # both ranks are still in step with each other
+    dist.destroy_process_group()
+
+
+def test_synthesize_sharded_one_failing_rank_fails_all_ranks(tmp_path):
+    """An engine error on one rank must not leave the others waiting in the gather: every rank raises."""
+    port = free_port()
+    mp.spawn(_failing_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert "rank 1 failed" in (tmp_path / "raised1.txt").read_text()
+    assert "another rank failed" in (tmp_path / "raised0.txt").read_text()
+
+
 def test_bench_multi_rank_branch_contract_world2():
     """bench.py's N > 1 branch on CPU: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with E2ETTS_BENCH_STUB=1
     (a stand-in engine that computes nothing) under gloo -- rendezvous from the env, weight broadcast from rank 0, barrier-bracketed

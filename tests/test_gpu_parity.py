@@ -974,3 +974,82 @@ def test_parallel_key_segments_match_the_in_register_merge(tmp_path):
     o = np.load(out)
     np.testing.assert_array_equal(o["mel_post"], mel_post)
     np.testing.assert_array_equal(o["pcm"], pcm)
+
+
+def _random_geometry(seed):
+    """A small model whose every dimension differs from the two fixture configurations: head dim 32 .. 192, FFN / predictor / postnet widths
+    that are no multiple of 32, kernel sizes 3 .. 9, 2 .. 4 vocoder stages of assorted rates, 1 .. 3 ResBlocks with 1 .. 3 dilations."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]   # noqa: E731
+    cfg = cfgmod.tiny_config()
+    fs = cfg["models"]["fastspeech2"]
+    hidden, heads = pick([(64, 2), (96, 1), (128, 2), (192, 1), (128, 1), (96, 3), (192, 2)])
+    fs["encoder_hidden"] = fs["decoder_hidden"] = hidden
+    fs["encoder_layers"], fs["decoder_layers"] = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    tr = fs["building_block"]["transformer"]
+    tr["encoder_head"] = tr["decoder_head"] = heads
+    tr["conv_filter_size"] = pick([64, 100, 136, 160])
+    tr["conv_kernel_size"] = [pick([3, 5, 9]), 1]
+    vp = fs["variance"]["variance_predictor"]
+    vp["filter_size"] = pick([32, 44, 64])
+    vp["dur_predictor_layers"] = int(rng.integers(1, 4))
+    vp["pit_predictor_layers"] = vp["ener_predictor_layers"] = int(rng.integers(1, 4))   # (the engine wants pitch and energy alike)
+    vp["dur_predictor_kernel"] = pick([3, 5])
+    vp["pit_predictor_kernel"] = vp["ener_predictor_kernel"] = pick([3, 5])
+    fs["postnet"].update(embedding_dim=pick([32, 44, 60]), conv_layers=int(rng.integers(2, 6)), kernel_size=pick([3, 5, 7]))
+    rates = pick([[4, 4], [2, 2, 2], [8, 2], [4, 2, 2, 2], [2, 4, 2]])
+    nk = int(rng.integers(1, 4))
+    nd = int(rng.integers(1, 4))
+    hg = cfg["models"]["hifigan"]
+    hg.update(upsample_rates=rates, upsample_kernel_sizes=[2 * r for r in rates], upsample_initial_channel=pick([64, 128]),
+              resblock_kernel_sizes=[pick([3, 5, 7, 11]) for _ in range(nk)],
+              resblock_dilation_sizes=[[pick([1, 2, 3, 5]) for _ in range(nd)] for _ in range(nk)])
+    cfg["audio"]["stft"]["hop_length"] = int(np.prod(rates))
+    return cfg
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_model_geometries_match_the_oracle(seed):
+    """HIP vs the numpy oracle on model geometries no fixture has (the oracle is pinned by the fixtures' two configurations; the kernels
+    take every dimension from the config, reference U/model.py:20-60, V/generator.py:14-35): discrete outputs exact on ids chosen away from
+    the rounding boundaries (the fixtures' own margin search), mel / waveform within the fp32 bars in both arithmetic modes, and ragged
+    compute bit-identical to the padded batch on valid samples."""
+    from e2e_tts_amd import synth_weights as sw
+    from e2e_tts_amd.runtime import engine_from_states
+    from oracle import ref_numpy as orc
+    from oracle.make_goldens import search_ids
+    cfg = _random_geometry(seed)
+    stats = cfgmod.DEFAULT_STATS
+    ac = sw.make_acoustic_state(cfg, stats, 4, seed=700 + seed, mode="varied")
+    voc = sw.make_vocoder_state(cfg, seed=800 + seed)
+    o = orc.AcousticOracle(ac, cfg, stats)
+    lens = np.array([[29, 7, 18], [33, 33, 1, 12], [5, 40]][seed % 3], np.int64)
+    spk_id = seed % 4
+    _, ids = search_ids(o, [int(x) for x in lens], spk_id, stats, (1.0, 1.0, 1.0), 2e-3, 40, 5000 + 100 * seed, False)
+    spk = np.array([spk_id], np.int64)
+    (omel, omel_post, odur), omel_lens = o.inference(spk, ids, lens)
+    owav = orc.VocoderOracle(voc, cfg).forward(omel_post.transpose(0, 2, 1))[:, 0]
+    hop = cfg["audio"]["stft"]["hop_length"]
+    eng = engine_from_states(cfg, stats, ac, voc)
+    try:
+        for prec in PRECISIONS:
+            eng.set_precision(prec)
+            r = eng.acoustic(ids, lens, spk, want=("dur", "mel_lens", "pitch_idx", "energy_idx"))
+            np.testing.assert_array_equal(r["dur"], odur)
+            np.testing.assert_array_equal(r["mel_lens"], omel_lens)
+            np.testing.assert_array_equal(r["pitch_idx"], o.trace["pitch_idx"])
+            np.testing.assert_array_equal(r["energy_idx"], o.trace["energy_idx"])
+            mel, mel_post = eng.fetch_mel(r["B"], r["T"])
+            assert mean_l1(mel_post, omel_post) < MEL_L1, (seed, prec, mean_l1(mel_post, omel_post))
+            wav, _ = eng.vocoder(None, r["B"], r["T"])
+            assert mean_l1(wav, owav) < WAV_L1, (seed, prec, mean_l1(wav, owav))
+            eng.set_ragged(False)
+            full, ml, T = eng.synthesize(ids, lens, spk)
+            eng.set_ragged(True)
+            eng.poison_workspace()
+            rag, ml2, T2 = eng.synthesize(ids, lens, spk)
+            assert T == T2 and np.array_equal(ml, ml2) and np.array_equal(ml, omel_lens)
+            for b, n in enumerate(ml * hop):
+                np.testing.assert_array_equal(rag[b, :n], full[b, :n])
+    finally:
+        eng.close()

@@ -1005,13 +1005,19 @@ def _random_geometry(seed):
               resblock_kernel_sizes=[pick([3, 5, 7, 11]) for _ in range(nk)],
               resblock_dilation_sizes=[[pick([1, 2, 3, 5]) for _ in range(nd)] for _ in range(nk)])
     cfg["audio"]["stft"]["hop_length"] = int(np.prod(rates))
+    if seed >= 100:   # Conformer blocks (U/blocks/conformer.py:31-36): head dims 8 .. 96, depthwise kernels with and without a fused instantiation
+        hidden, heads = pick([(64, 8), (64, 4), (96, 2), (128, 4), (96, 1), (192, 4)])
+        fs["encoder_hidden"] = fs["decoder_hidden"] = hidden
+        fs["building_block"]["block_type"] = "conformer"
+        fs["building_block"]["conformer"].update(encoder_head=heads, decoder_head=heads, ffn_expansion_factor=pick([2, 4]),
+                                                 conv_kernel_size=pick([5, 7, 9, 15, 31]))
     return cfg
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 101, 102, 103])
 def test_random_model_geometries_match_the_oracle(seed):
     """HIP vs the numpy oracle on model geometries no fixture has (the oracle is pinned by the fixtures' two configurations; the kernels
-    take every dimension from the config, reference U/model.py:20-60, V/generator.py:14-35): discrete outputs exact on ids chosen away from
+    take every dimension from the config, reference U/model.py:20-60, V/generator.py:14-35; seeds >= 100: Conformer blocks): discrete outputs exact on ids chosen away from
     the rounding boundaries (the fixtures' own margin search), mel / waveform within the fp32 bars in both arithmetic modes, and ragged
     compute bit-identical to the padded batch on valid samples."""
     from e2e_tts_amd import synth_weights as sw

@@ -194,6 +194,8 @@ class CEngineConfig(ctypes.Structure):
         ("voc_istft_nfft", ctypes.c_int32),
         ("voc_istft_hop", ctypes.c_int32),
         ("block_type", ctypes.c_int32),
+        ("energy_layers", ctypes.c_int32),
+        ("energy_kernel", ctypes.c_int32),
     ]
 
 
@@ -233,6 +235,8 @@ class EngineDims:
     voc_resblock: int = 1     # 1: ResBlock1, 2: ResBlock2 (reference V/layers.py)
     voc_istft_nfft: int = 0   # 0: HiFi-GAN tail; else iSTFTNet (reference V/generator.py:65-113)
     voc_istft_hop: int = 0
+    energy_layers: int = 0    # energy predictor depth / kernel when they differ from the pitch predictor's (0: the same; U/layers.py:92,96)
+    energy_kernel: int = 0
     cf_ffn_factor: float = 0.5  # Conformer half_step_residual (U/blocks/conformer.py:209-212); folded into the weights by the packer
     block_type: int = 0       # 0: FFT block (U/blocks/transformer.py), 1: Conformer block (U/blocks/conformer.py); then ffn_dim =
                               # hidden x ffn_expansion_factor and ffn_k1 = the depthwise kernel size
@@ -261,6 +265,7 @@ class EngineDims:
         c.f0_std = float(self.f0_std)
         c.voc_resblock, c.voc_istft_nfft, c.voc_istft_hop = int(self.voc_resblock), int(self.voc_istft_nfft), int(self.voc_istft_hop)
         c.block_type = int(self.block_type)
+        c.energy_layers, c.energy_kernel = int(self.energy_layers), int(self.energy_kernel)
         if len(self.voc_up_rate) > MAX_STAGES or len(self.voc_rb_kernel) > MAX_RESBLOCK_KERNELS:
             raise ValueError("vocoder config exceeds the C-ABI limits")
         c.voc_stages = len(self.voc_up_rate)
@@ -318,8 +323,6 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
     vp = var["variance_predictor"]
     if vp["ffn_padding"] != "SAME":
         raise NotImplementedError("ffn_padding must be 'SAME'")
-    if vp["pit_predictor_layers"] != vp["ener_predictor_layers"] or vp["pit_predictor_kernel"] != vp["ener_predictor_kernel"]:
-        raise NotImplementedError("pitch and energy predictors must share depth/kernel")
     # HifiGan picks ResBlock1 for `config['resblock'] == 1` (V/generator.py:19); iSTFT compares with the STRING '1'
     # (V/generator.py:71), so the shipped yaml (an int) gives it ResBlock2 -- reproduced, checkpoints depend on it
     rb1 = (hg["resblock"] == "1") if vocoder == "istft" else (hg["resblock"] == 1)
@@ -354,6 +357,7 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         pos_table_rows=pos_table_rows,
         f0_mean=float(stats["f0"]["mean"]), f0_std=float(stats["f0"]["std"]),
         block_type=1 if bt == "conformer" else 0,
+        energy_layers=vp["ener_predictor_layers"], energy_kernel=vp["ener_predictor_kernel"],
         cf_ffn_factor=(0.5 if tr.get("half_step_residual", True) else 1.0),
     )
     if dims.ffn_k2 != 1:

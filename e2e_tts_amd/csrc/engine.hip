@@ -493,7 +493,8 @@ int bind_acoustic(e2etts_engine* e) {
   }
   RET(bind_pred(e, "dur", c.dur_layers, c.dur_kernel, c.dur_chans, 1, false, e->dur));
   RET(bind_pred(e, "pitch", c.var_layers, c.var_kernel, c.var_chans, 2, true, e->pitch));
-  RET(bind_pred(e, "energy", c.var_layers, c.var_kernel, c.var_chans, 1, true, e->energy));
+  RET(bind_pred(e, "energy", c.energy_layers ? c.energy_layers : c.var_layers, c.energy_kernel ? c.energy_kernel : c.var_kernel, c.var_chans, 1, true,
+                e->energy));
   {
     auto it = e->tensors.find("var.pos");
     if (it == e->tensors.end()) return e->fail(E2ETTS_EKEY, "weight blob has no tensor 'var.pos'");
@@ -873,7 +874,9 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     e->h_act.resize((size_t)(5 + c.voc_stages) * B, 0);
     int32_t* he = e->h_act.data() + (size_t)(3 + c.voc_stages) * B;
     int32_t* hv = he + B;
-    const int add_var = (c.var_layers - 1) * ((c.var_kernel - 1) / 2);
+    // (one limit for both variance predictors: the deeper reach of the two)
+    const int add_var = std::max((c.var_layers - 1) * ((c.var_kernel - 1) / 2),
+                                 ((c.energy_layers ? c.energy_layers : c.var_layers) - 1) * (((c.energy_kernel ? c.energy_kernel : c.var_kernel) - 1) / 2));
     double se = 0, sv = 0;
     for (int b = 0; b < B; ++b) {
       he[b] = (int32_t)std::min<long long>(std::max<long long>(lens[b], 0), L);   // lens_to_i32_kernel's clamp

@@ -81,6 +81,8 @@ inline const char* config_check(const e2etts_config& c) {
   if (c.ffn_k2 != 1 || !in(c.ffn_k1, 1, 255) || !(c.ffn_k1 & 1)) return "FFN kernels must be (odd, 1)";
   if (!in(c.dur_layers, 1, 16) || !in(c.var_layers, 1, 16) || !in(c.dur_kernel, 1, 255) || !in(c.var_kernel, 1, 255) || !(c.dur_kernel & 1) || !(c.var_kernel & 1))
     return "predictor layer counts / kernels out of range";
+  if ((c.energy_layers != 0 && !in(c.energy_layers, 1, 16)) || (c.energy_kernel != 0 && (!in(c.energy_kernel, 1, 255) || !(c.energy_kernel & 1))))
+    return "energy predictor layer count / kernel out of range";
   if (!in(c.postnet_layers, 1, 16) || !in(c.postnet_kernel, 1, 255) || !(c.postnet_kernel & 1)) return "postnet layers / kernel out of range";
   if (!in(c.voc_stages, 1, E2ETTS_MAX_STAGES) || !in(c.voc_n_kernels, 1, E2ETTS_MAX_RB_KERNELS) || !in(c.voc_n_dil, 1, E2ETTS_MAX_DILATIONS))
     return "vocoder stage / kernel / dilation counts out of range";

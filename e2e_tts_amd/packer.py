@@ -244,7 +244,7 @@ def _pack_acoustic(dims: EngineDims, A, out) -> None:
     for name, short, layers, kern, chans, odim in (
             ("duration_predictor", "dur", dims.dur_layers, dims.dur_kernel, dims.dur_chans, 1),
             ("pitch_predictor", "pitch", dims.var_layers, dims.var_kernel, dims.var_chans, 2),
-            ("energy_predictor", "energy", dims.var_layers, dims.var_kernel, dims.var_chans, 1)):
+            ("energy_predictor", "energy", dims.energy_layers or dims.var_layers, dims.energy_kernel or dims.var_kernel, dims.var_chans, 1)):
         for i in range(layers):
             cin = H if i == 0 else chans
             p = f"{va}.{name}.conv.{i}"

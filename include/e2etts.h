@@ -58,7 +58,7 @@ typedef struct e2etts_config {
   int32_t ffn_k1, ffn_k2; /* conv_kernel_size */
   int32_t max_seq_len;
   int32_t dur_layers, dur_kernel, dur_chans;
-  int32_t var_layers, var_kernel, var_chans;
+  int32_t var_layers, var_kernel, var_chans; /* pitch predictor (and the energy predictor unless energy_layers / energy_kernel say otherwise); filter_size */
   int32_t n_bins;
   int32_t postnet_layers, postnet_dim, postnet_kernel;
   int32_t voc_init_ch;
@@ -80,6 +80,8 @@ typedef struct e2etts_config {
   int32_t block_type;     /* encoder / decoder block: 0 = FFT block (U/blocks/transformer.py:178-189); 1 = Conformer block
                              (U/blocks/conformer.py:171-255): n_head relative-position heads, ffn_dim = hidden x ffn_expansion_factor,
                              ffn_k1 = depthwise kernel size */
+  int32_t energy_layers;  /* energy predictor depth / kernel (U/layers.py:92,96: ener_predictor_layers / ener_predictor_kernel); 0 = the pitch */
+  int32_t energy_kernel;  /* predictor's (var_layers / var_kernel, U/layers.py:54,58), which is what the shipped model_config.yaml has */
 } e2etts_config;
 
 /* Threading: every entry point takes the engine's internal mutex, so single calls are safe from any thread and distinct engines are

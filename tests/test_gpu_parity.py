@@ -993,9 +993,11 @@ def _random_geometry(seed):
     vp = fs["variance"]["variance_predictor"]
     vp["filter_size"] = pick([32, 44, 64])
     vp["dur_predictor_layers"] = int(rng.integers(1, 4))
-    vp["pit_predictor_layers"] = vp["ener_predictor_layers"] = int(rng.integers(1, 4))   # (the engine wants pitch and energy alike)
+    vp["pit_predictor_layers"] = vp["ener_predictor_layers"] = int(rng.integers(1, 4))
     vp["dur_predictor_kernel"] = pick([3, 5])
     vp["pit_predictor_kernel"] = vp["ener_predictor_kernel"] = pick([3, 5])
+    if seed % 2 == 0:   # energy predictor of its own depth / kernel (U/layers.py:92,96)
+        vp["ener_predictor_layers"], vp["ener_predictor_kernel"] = int(rng.integers(1, 4)), pick([3, 5, 7])
     fs["postnet"].update(embedding_dim=pick([32, 44, 60]), conv_layers=int(rng.integers(2, 6)), kernel_size=pick([3, 5, 7]))
     rates = pick([[4, 4], [2, 2, 2], [8, 2], [4, 2, 2, 2], [2, 4, 2]])
     nk = int(rng.integers(1, 4))

@@ -196,6 +196,7 @@ class CEngineConfig(ctypes.Structure):
         ("block_type", ctypes.c_int32),
         ("energy_layers", ctypes.c_int32),
         ("energy_kernel", ctypes.c_int32),
+        ("dec_n_head", ctypes.c_int32),
     ]
 
 
@@ -237,6 +238,7 @@ class EngineDims:
     voc_istft_hop: int = 0
     energy_layers: int = 0    # energy predictor depth / kernel when they differ from the pitch predictor's (0: the same; U/layers.py:92,96)
     energy_kernel: int = 0
+    dec_n_head: int = 0       # decoder_head when it differs from encoder_head (0: the same; U/blocks/transformer.py:105)
     cf_ffn_factor: float = 0.5  # Conformer half_step_residual (U/blocks/conformer.py:209-212); folded into the weights by the packer
     block_type: int = 0       # 0: FFT block (U/blocks/transformer.py), 1: Conformer block (U/blocks/conformer.py); then ffn_dim =
                               # hidden x ffn_expansion_factor and ffn_k1 = the depthwise kernel size
@@ -266,6 +268,7 @@ class EngineDims:
         c.voc_resblock, c.voc_istft_nfft, c.voc_istft_hop = int(self.voc_resblock), int(self.voc_istft_nfft), int(self.voc_istft_hop)
         c.block_type = int(self.block_type)
         c.energy_layers, c.energy_kernel = int(self.energy_layers), int(self.energy_kernel)
+        c.dec_n_head = int(self.dec_n_head)
         if len(self.voc_up_rate) > MAX_STAGES or len(self.voc_rb_kernel) > MAX_RESBLOCK_KERNELS:
             raise ValueError("vocoder config exceeds the C-ABI limits")
         c.voc_stages = len(self.voc_up_rate)
@@ -308,8 +311,6 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         if tr["conv_kernel_size"] % 2 != 1:
             raise ValueError("conformer conv_kernel_size must be odd (reference U/blocks/conformer.py:465)")
         tr = dict(tr, conv_filter_size=fs["encoder_hidden"] * tr["ffn_expansion_factor"], conv_kernel_size=[tr["conv_kernel_size"], 1])
-    if tr["encoder_head"] != tr["decoder_head"]:
-        raise NotImplementedError("encoder_head != decoder_head")
     if fs["encoder_hidden"] != fs["decoder_hidden"]:
         raise NotImplementedError("encoder_hidden != decoder_hidden")
     var = fs["variance"]
@@ -358,6 +359,7 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         f0_mean=float(stats["f0"]["mean"]), f0_std=float(stats["f0"]["std"]),
         block_type=1 if bt == "conformer" else 0,
         energy_layers=vp["ener_predictor_layers"], energy_kernel=vp["ener_predictor_kernel"],
+        dec_n_head=tr["decoder_head"],
         cf_ffn_factor=(0.5 if tr.get("half_step_residual", True) else 1.0),
     )
     if dims.ffn_k2 != 1:
@@ -370,6 +372,6 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
             raise NotImplementedError("gen_istft_n_fft must be a power of two in [4, 256] and a multiple of gen_istft_hop_size")
     if dims.upsample_total != hop:
         raise ValueError(f"product of upsample_rates (x iSTFT hop) ({dims.upsample_total}) != hop_length ({hop})")
-    if dims.hidden % dims.n_head:
+    if dims.hidden % dims.n_head or dims.hidden % (dims.dec_n_head or dims.n_head):
         raise ValueError("hidden not divisible by heads")
     return dims

@@ -415,9 +415,9 @@ int bind_cf_gemm(e2etts_engine* e, const std::string& name, const char* bias, ui
   return E2ETTS_OK;
 }
 
-int bind_conformer(e2etts_engine* e, const char* side, int layers, std::vector<CfLayer>& v) {
+int bind_conformer(e2etts_engine* e, const char* side, int layers, std::vector<CfLayer>& v, int n_head) {
   const auto& c = e->cfg;
-  const uint64_t H = c.hidden, F = c.ffn_dim, nh = c.n_head;
+  const uint64_t H = c.hidden, F = c.ffn_dim, nh = n_head;
   v.resize(layers);
   for (int l = 0; l < layers; ++l) {
     const std::string p = std::string(side) + "." + std::to_string(l) + ".";
@@ -485,8 +485,8 @@ int bind_acoustic(e2etts_engine* e) {
   RET(get_tensor(e, "pos.regen", (uint64_t)c.pos_table_rows * H, &e->pos_regen));
   RET(get_tensor(e, "spk.emb", (uint64_t)c.n_speakers * H, &e->spk_emb));
   if (c.block_type == 1) {
-    RET(bind_conformer(e, "enc", c.enc_layers, e->cf_enc));
-    RET(bind_conformer(e, "dec", c.dec_layers, e->cf_dec));
+    RET(bind_conformer(e, "enc", c.enc_layers, e->cf_enc, c.n_head));
+    RET(bind_conformer(e, "dec", c.dec_layers, e->cf_dec, c.dec_n_head ? c.dec_n_head : c.n_head));
   } else {
     RET(bind_fft(e, "enc", c.enc_layers, e->enc));
     RET(bind_fft(e, "dec", c.dec_layers, e->dec));
@@ -622,7 +622,7 @@ int bind_vocoder(e2etts_engine* e) {
 }
 
 // 6 x FFTBlock (reference U/blocks/transformer.py:178-189), in place on x ([B, N, H]); lens32: device [B]
-int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3,
+int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, int n_head, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3,
               const int32_t* act = nullptr, double act_frac = 1.0, bool ksplit = false, const int32_t* act_host = nullptr) {
   const auto& c = e->cfg;
   const int H = c.hidden, F = c.ffn_dim;
@@ -638,16 +638,16 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
     p.in = x; p.w = sx ? f.wqkv_x3 : f.wqkv; p.x3 = sx; p.bias = f.bqkv; p.out = qkv; p.Cin = H; p.Cout = 3 * H;
     RET(conv(e, p, 1.0, ksplit));
     {
-      const double fl = 4.0 * B * c.n_head * (double)N * N * (H / c.n_head);
+      const double fl = 4.0 * B * n_head * (double)N * N * (H / n_head);
       ProfScope ps(e, sx ? "attention_x3" : "attention", fl, 4.0 * 4.0 * B * N * H);
       float* aws = nullptr;   // workspace for the parallel key segments of small fp32 grids (attention.hip); 3.6 MB at B = 1, T = 768
       size_t aws_bytes = 0;
-      if (!sx && !act_host && (long long)B * ((N + 63) / 64) * c.n_head <= attention_par_max_grid() && N > 32 * 8) {
-        aws_bytes = attention_workspace_bytes(B, N, H, c.n_head);
+      if (!sx && !act_host && (long long)B * ((N + 63) / 64) * n_head <= attention_par_max_grid() && N > 32 * 8) {
+        aws_bytes = attention_workspace_bytes(B, N, H, n_head);
         RET(ensure(e, e->attws, aws_bytes));
         aws = ptr<float>(e->attws);
       }
-      KCHK(e, launch_attention(qkv, att, lens, B, N, H, c.n_head, sx ? 1 : 0, e->stream, act_host, aws, aws_bytes));
+      KCHK(e, launch_attention(qkv, att, lens, B, N, H, n_head, sx ? 1 : 0, e->stream, act_host, aws, aws_bytes));
     }
     // fc + residual (:238-239), LayerNorm eps 1e-5, masked_fill (:182-183)
     p = ConvParams(); p.B = B; p.T = N; p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;
@@ -676,9 +676,9 @@ int fft_stack(e2etts_engine* e, const std::vector<FFTLayer>& layers, float* x, f
 // n x ConformerBlock (reference U/blocks/conformer.py:214-255), in place on x ([B, N, H]).  Every sub-module is a pre-norm residual
 // unit; nothing inside a block is masked (nn.Sequential hands the attention module no mask, :252, and the depthwise convolution
 // runs over the padded length), so all N rows are computed; only the block's final LayerNorm output is zeroed at rows >= lens[b].
-int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3) {
+int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, int n_head, float* x, float* xalt, const int32_t* lens, int B, int N, bool x3) {
   const auto& c = e->cfg;
-  const int H = c.hidden, F = c.ffn_dim, nh = c.n_head, dh = H / nh;
+  const int H = c.hidden, F = c.ffn_dim, nh = n_head, dh = H / nh;
   float* qkv = ptr<float>(e->qkv);
   float* att = ptr<float>(e->att);
   float* tmp = ptr<float>(e->tmp);
@@ -890,8 +890,8 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     frac_enc = se / ((double)B * L);
     frac_var = sv / ((double)B * L);
   }
-  if (c.block_type == 1) RET(conformer_stack(e, e->cf_enc, x, ptr<float>(e->xb), tl, B, L, false));
-  else RET(fft_stack(e, e->enc, x, ptr<float>(e->xb), tl, B, L, false, act_enc, frac_enc, true, act_enc_h));  // encoder: always exact fp32, K-split kernel
+  if (c.block_type == 1) RET(conformer_stack(e, e->cf_enc, c.n_head, x, ptr<float>(e->xb), tl, B, L, false));
+  else RET(fft_stack(e, e->enc, c.n_head, x, ptr<float>(e->xb), tl, B, L, false, act_enc, frac_enc, true, act_enc_h));  // encoder: always exact fp32, K-split kernel
 
   // Variance adaptor, inference branch (U/layers.py:195-258)
   float* xs = ptr<float>(e->xs);
@@ -990,8 +990,9 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     e->rag_frac_voc = sv / ((double)B * T);
   }
   // (a Conformer decoder computes every row: its attention is unmasked and its depthwise convolution crosses into the padding)
-  if (c.block_type == 1) RET(conformer_stack(e, e->cf_dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1));
-  else RET(fft_stack(e, e->dec, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1, act_dec, act_dec ? e->rag_frac_dec : 1.0, false, act_dec_h));
+  const int dec_heads = c.dec_n_head ? c.dec_n_head : c.n_head;
+  if (c.block_type == 1) RET(conformer_stack(e, e->cf_dec, dec_heads, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1));
+  else RET(fft_stack(e, e->dec, dec_heads, dx, ptr<float>(e->dxb), ml, B, (int)T, e->dec_precision == 1, act_dec, act_dec ? e->rag_frac_dec : 1.0, false, act_dec_h));
   // mel_linear (U/model.py:186)
   ConvParams p;
   auto setw = [&](ConvParams& q, const ConvW& w) {

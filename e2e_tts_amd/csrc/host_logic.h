@@ -101,9 +101,11 @@ inline const char* config_check(const e2etts_config& c) {
     if (n < 4 || n > 256 || (n & (n - 1)) || !in(c.voc_istft_hop, 1, 256) || n % c.voc_istft_hop) return "iSTFT: n_fft must be a power of two in [4, 256] and a multiple of the hop";
   }
   if (c.block_type != 0 && c.block_type != 1) return "block_type must be 0 (FFT block) or 1 (Conformer block)";
+  if (c.dec_n_head != 0 && (!in(c.dec_n_head, 1, BIG) || c.hidden % c.dec_n_head)) return "hidden must be a multiple of dec_n_head";
   if (c.block_type == 1) {
-    const int dh = c.hidden / c.n_head;
-    if (dh != 8 && dh != 16 && dh != 32 && dh != 48 && dh != 64 && dh != 96) return "Conformer head dim must be one of 8, 16, 32, 48, 64, 96";
+    const int dh = c.hidden / c.n_head, dhd = c.hidden / (c.dec_n_head ? c.dec_n_head : c.n_head);
+    for (int d : {dh, dhd})
+      if (d != 8 && d != 16 && d != 32 && d != 48 && d != 64 && d != 96) return "Conformer head dim must be one of 8, 16, 32, 48, 64, 96";
     if (c.ffn_dim < 2 * c.hidden) return "Conformer ffn_expansion_factor must be at least 2";
   }
   if (c.n_bins != 256) return "n_bins must be 256";

@@ -155,11 +155,12 @@ def _pack_conformer(dims: EngineDims, A, out) -> None:
     pos_proj(position table) per layer -- it does not depend on the input -- laid out per head [n_head][rows][d_head], once from
     the stored table (`att.pos`, N <= max_seq_len) and once from the regenerated one (`att.posr`, conformer.py:339-344).  u_bias and
     v_bias travel as they are (`att.u`, `att.v`, heads flattened): the attention kernel adds them to its query fragments."""
-    H, F, nh, k = dims.hidden, dims.ffn_dim, dims.n_head, dims.ffn_k1
-    dh = H // nh
+    H, F, k = dims.hidden, dims.ffn_dim, dims.ffn_k1
     need = _need
     regen = sinusoid_table(dims.pos_table_rows, H)
     for side, short, n in (("encoder", "enc", dims.enc_layers), ("decoder", "dec", dims.dec_layers)):
+        nh = (dims.dec_n_head or dims.n_head) if short == "dec" else dims.n_head   # encoder_head / decoder_head (conformer.py:31,108)
+        dh = H // nh
         for l in range(n):
             s = f"{side}.layer_stack.{l}.sequential"
             q = f"{short}.{l}."

@@ -82,6 +82,8 @@ typedef struct e2etts_config {
                              ffn_k1 = depthwise kernel size */
   int32_t energy_layers;  /* energy predictor depth / kernel (U/layers.py:92,96: ener_predictor_layers / ener_predictor_kernel); 0 = the pitch */
   int32_t energy_kernel;  /* predictor's (var_layers / var_kernel, U/layers.py:54,58), which is what the shipped model_config.yaml has */
+  int32_t dec_n_head;     /* attention heads of the decoder's blocks (decoder_head, U/blocks/transformer.py:105, conformer.py:108); 0 = n_head, which then
+                             is both encoder_head and decoder_head */
 } e2etts_config;
 
 /* Threading: every entry point takes the engine's internal mutex, so single calls are safe from any thread and distinct engines are

@@ -536,6 +536,8 @@ def main():
     tiny_cf, full_cf = cfgmod.tiny_config(), cfgmod.default_config()   # block_type "conformer" (U/model.py:26-27)
     for c in (tiny_cf, full_cf):
         c["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"
+    tiny_hv, tiny_cf_hv = hv_variant(cfgmod.tiny_config()), hv_variant(cfgmod.tiny_config())
+    tiny_cf_hv["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"
     jobs = {
         "tables": lambda: case_tables(models),
         "host_loop": case_host_loop,
@@ -551,6 +553,8 @@ def main():
         "tiny_cf_b3": lambda: case_model(models, "tiny_cf_b3", tiny_cf, "varied", [23, 17, 9], 1, (1.0, 1.0, 1.0), 600, 2e-3, "full"),
         "tiny_cf_long": lambda: case_model(models, "tiny_cf_long", tiny_cf, "varied", [70, 33], 2, (1.1, 0.9, 1.2), 700, 2e-3, "full"),
         "full_cf_b2": lambda: case_model(models, "full_cf_b2", full_cf, "varied", [40, 27], 1, (1.0, 1.0, 1.0), 800, 1e-3, "medium"),
+        "tiny_hv_b3": lambda: case_model(models, "tiny_hv_b3", tiny_hv, "varied", [21, 13, 30], 1, (1.0, 1.0, 1.0), 1100, 2e-3, "full"),
+        "tiny_cf_hv_b3": lambda: case_model(models, "tiny_cf_hv_b3", tiny_cf_hv, "varied", [21, 13, 30], 2, (1.0, 1.0, 1.0), 1200, 2e-3, "full"),
         "c1_plumbing": lambda: case_model(models, "c1_plumbing", full, "varied", [40], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
         "full_b3": lambda: case_model(models, "full_b3", full, "varied", [48, 31, 20], 1, (1.0, 1.0, 1.0), 500, 1e-3, "medium"),
     }
@@ -568,6 +572,17 @@ def main():
         if args.only and name != args.only:
             continue
         fn()
+
+
+def hv_variant(cfg):
+    """Fixtures `*_hv_*`: decoder_head != encoder_head (U/blocks/transformer.py:29,105, conformer.py:31,108) and an energy predictor whose
+    depth / kernel differ from the pitch predictor's (U/layers.py:54-58,92-96) -- knobs the reference's config has and its shipped yaml leaves equal."""
+    fs = cfg["models"]["fastspeech2"]
+    bb = fs["building_block"]
+    bb["transformer"].update(encoder_head=2, decoder_head=1)     # hidden 64: head dims 32 / 64
+    bb["conformer"].update(encoder_head=4, decoder_head=2)       # head dims 16 / 32
+    fs["variance"]["variance_predictor"].update(ener_predictor_layers=3, ener_predictor_kernel=3)
+    return cfg
 
 
 def c3_lengths():

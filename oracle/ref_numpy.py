@@ -340,6 +340,7 @@ class AcousticOracle:
 
     # U/blocks/transformer.py:58-86
     def encoder(self, ids: np.ndarray, pad: np.ndarray) -> np.ndarray:
+        self.n_head = self.tr["encoder_head"]                            # U/blocks/transformer.py:29, conformer.py:31
         x = self.sd["encoder.src_word_emb.weight"][ids] + self._pos_enc("encoder", ids.shape[1])[None]
         for l in range(self.fs["encoder_layers"]):
             x = self.block(f"encoder.layer_stack.{l}", x, pad)
@@ -347,6 +348,7 @@ class AcousticOracle:
 
     # U/blocks/transformer.py:132-164
     def decoder(self, x: np.ndarray, pad: np.ndarray) -> np.ndarray:
+        self.n_head = self.tr["decoder_head"]                            # U/blocks/transformer.py:105, conformer.py:108
         x = x + self._pos_enc("decoder", x.shape[1])[None]
         for l in range(self.fs["decoder_layers"]):
             x = self.block(f"decoder.layer_stack.{l}", x, pad)

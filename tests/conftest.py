@@ -33,6 +33,9 @@ def config_for(name):
     cfg = cfgmod.tiny_config() if name.startswith("tiny") or name.startswith("voc_micro") else cfgmod.default_config()
     if "_cf_" in name:  # fixtures made with building_block.block_type = "conformer" (oracle/make_goldens.py)
         cfg["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"
+    if "_hv_" in name:  # decoder_head != encoder_head, energy predictor of its own depth / kernel (oracle/make_goldens.py: hv_variant)
+        from oracle.make_goldens import hv_variant
+        cfg = hv_variant(cfg)
     return cfg
 
 
@@ -43,7 +46,7 @@ def states_for(g, name):
     """Regenerate the synthetic state dicts a fixture was made with (seeds + mode are stored in it)."""
     from e2e_tts_amd import config as cfgmod, synth_weights as sw
     cfg = config_for(name)
-    key = (name.startswith("tiny"), "_cf_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
+    key = (name.startswith("tiny"), "_cf_" in name, "_hv_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
     if key not in _STATE_CACHE:
         ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=int(g["weight_seeds"][0]), mode=str(g["mode"]))
         voc = sw.make_vocoder_state(cfg, seed=int(g["weight_seeds"][1]))

@@ -78,7 +78,7 @@ def test_tts_from_checkpoint_files_matches_oracle(tmp_path):
             assert 0.3 * (n1 - silence) <= n2 - silence <= 0.7 * (n1 - silence)
 
 
-@pytest.mark.parametrize("name", ["tiny_b3", "tiny_cf_b3"])  # FFT blocks / Conformer blocks (config-selected, U/model.py:24-27)
+@pytest.mark.parametrize("name", ["tiny_b3", "tiny_cf_b3", "tiny_hv_b3"])  # FFT blocks / Conformer blocks (config-selected, U/model.py:24-27) / heads + energy predictor of their own
 def test_model_mirrors_match_reference_fixture(name):
     import torch
     from e2e_tts_amd.models import HifiGan, UnsupervisedFastSpeech2

@@ -22,7 +22,7 @@ _ENGINES = {}
 def engine_for(g, name):
     from e2e_tts_amd.runtime import engine_from_states
     cfg, ac, voc = states_for(g, name)
-    key = (name.startswith("tiny"), "_cf_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
+    key = (name.startswith("tiny"), "_cf_" in name, "_hv_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
     if key not in _ENGINES:
         _ENGINES[key] = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)
     return cfg, _ENGINES[key]
@@ -51,7 +51,7 @@ def check_discrete(r, g):
 
 # *_cf_*: the same model with Conformer blocks (building_block.block_type = "conformer", reference U/blocks/conformer.py);
 # tiny_cf_long runs past max_seq_len in the encoder and the decoder (regenerated position tables in every attention module)
-@pytest.mark.parametrize("name", ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1", "tiny_cf_b3", "tiny_cf_long"])
+@pytest.mark.parametrize("name", ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1", "tiny_cf_b3", "tiny_cf_long", "tiny_hv_b3", "tiny_cf_hv_b3"])
 def test_tiny_model_full_trace(name):
     g = load_golden(name)
     cfg, eng = engine_for(g, name)
@@ -557,7 +557,7 @@ def test_conformer_rejects_sequences_beyond_the_position_table():
         eng.acoustic(rng.integers(4, 131, size=(1, 100)).astype(np.int64), np.array([100], np.int64), np.array([0], np.int64))
 
 
-@pytest.mark.parametrize("name", ["tiny_b3", "tiny_ctl", "full_b3", "c3_mixed", "full_long", "tiny_cf_b3"])
+@pytest.mark.parametrize("name", ["tiny_b3", "tiny_ctl", "full_b3", "c3_mixed", "full_long", "tiny_cf_b3", "tiny_hv_b3", "tiny_cf_hv_b3"])
 def test_ragged_synthesize_is_bit_identical_on_valid_samples(name):
     """synthesize() with ragged compute (skip what no valid sample depends on) vs the full padded batch: same PCM on every
     valid sample, and within 1 LSB of the reference's waveform there."""
@@ -988,6 +988,8 @@ def _random_geometry(seed):
     fs["encoder_layers"], fs["decoder_layers"] = int(rng.integers(1, 3)), int(rng.integers(1, 3))
     tr = fs["building_block"]["transformer"]
     tr["encoder_head"] = tr["decoder_head"] = heads
+    if seed % 3 == 0:   # decoder_head of its own (U/blocks/transformer.py:105): any count whose head dim the attention kernels have
+        tr["decoder_head"] = pick([n for n in (1, 2, 3, 4, 6) if hidden % n == 0 and hidden // n in (32, 64, 96, 128, 192) and n != heads])
     tr["conv_filter_size"] = pick([64, 100, 136, 160])
     tr["conv_kernel_size"] = [pick([3, 5, 9]), 1]
     vp = fs["variance"]["variance_predictor"]
@@ -1013,6 +1015,9 @@ def _random_geometry(seed):
         fs["building_block"]["block_type"] = "conformer"
         fs["building_block"]["conformer"].update(encoder_head=heads, decoder_head=heads, ffn_expansion_factor=pick([2, 4]),
                                                  conv_kernel_size=pick([5, 7, 9, 15, 31]))
+        if seed % 2 == 0:
+            fs["building_block"]["conformer"]["decoder_head"] = pick([n for n in (1, 2, 4, 8, 12) if hidden % n == 0 and hidden // n in (8, 16, 32, 48, 64, 96)
+                                                                       and n != heads])
     return cfg
 
 

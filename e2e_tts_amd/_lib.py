@@ -255,7 +255,7 @@ class Engine:
             pitch_idx=np.empty((B, L), np.int32) if "pitch_idx" in want else None,
             energy_idx=np.empty((B, L), np.int32) if "energy_idx" in want else None,
             log_d=np.empty((B, L), np.float32) if "log_d" in want else None,
-            pitch_pred=np.empty((B, L, 2), np.float32) if "pitch_pred" in want else None,
+            pitch_pred=np.empty((B, L) if self.dims.pitch_no_uv else (B, L, 2), np.float32) if "pitch_pred" in want else None,
             energy_pred=np.empty((B, L), np.float32) if "energy_pred" in want else None,
         )
         T = C.c_int(0)

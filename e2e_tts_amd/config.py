@@ -197,6 +197,9 @@ class CEngineConfig(ctypes.Structure):
         ("energy_layers", ctypes.c_int32),
         ("energy_kernel", ctypes.c_int32),
         ("dec_n_head", ctypes.c_int32),
+        ("pitch_no_uv", ctypes.c_int32),
+        ("pitch_log2", ctypes.c_int32),
+        ("pitch_emb_rows", ctypes.c_int32),
     ]
 
 
@@ -239,6 +242,9 @@ class EngineDims:
     energy_layers: int = 0    # energy predictor depth / kernel when they differ from the pitch predictor's (0: the same; U/layers.py:92,96)
     energy_kernel: int = 0
     dec_n_head: int = 0       # decoder_head when it differs from encoder_head (0: the same; U/blocks/transformer.py:105)
+    pitch_no_uv: int = 0      # variance_embedding.use_uv False: one pitch output, bucketize on pitch_bins, f0_bins embedding rows (U/layers.py:136-160)
+    pitch_log2: int = 0       # use_uv with pitch_quantization "log": f0 = 2 ** prediction (U/layers.py:148-149)
+    pitch_emb_rows: int = 0   # rows of pitch_embedding when not n_bins
     cf_ffn_factor: float = 0.5  # Conformer half_step_residual (U/blocks/conformer.py:209-212); folded into the weights by the packer
     block_type: int = 0       # 0: FFT block (U/blocks/transformer.py), 1: Conformer block (U/blocks/conformer.py); then ffn_dim =
                               # hidden x ffn_expansion_factor and ffn_k1 = the depthwise kernel size
@@ -269,6 +275,7 @@ class EngineDims:
         c.block_type = int(self.block_type)
         c.energy_layers, c.energy_kernel = int(self.energy_layers), int(self.energy_kernel)
         c.dec_n_head = int(self.dec_n_head)
+        c.pitch_no_uv, c.pitch_log2, c.pitch_emb_rows = int(self.pitch_no_uv), int(self.pitch_log2), int(self.pitch_emb_rows)
         if len(self.voc_up_rate) > MAX_STAGES or len(self.voc_rb_kernel) > MAX_RESBLOCK_KERNELS:
             raise ValueError("vocoder config exceeds the C-ABI limits")
         c.voc_stages = len(self.voc_up_rate)
@@ -317,10 +324,10 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
     if not var["duration_modelling"]["learn_alignment"]:
         raise NotImplementedError("SupervisedFastSpeech2 is out of scope (reference API/utils.py:37-40)")
     ve = var["variance_embedding"]
-    if not ve["use_uv"] or ve["pitch_feature"] != "phoneme_level" or ve["energy_feature"] != "phoneme_level":
-        raise NotImplementedError("only use_uv=True, phoneme-level pitch/energy are implemented (reference U/layers.py:136-173)")
-    if ve["pitch_quantization"] != "linear":
-        raise NotImplementedError("pitch_quantization must be 'linear' (reference U/layers.py:151-152)")
+    if ve["pitch_feature"] != "phoneme_level" or ve["energy_feature"] != "phoneme_level":
+        raise NotImplementedError("only phoneme-level pitch/energy are implemented (reference U/layers.py:226-239; frame level: :249-257)")
+    if ve["pitch_quantization"] not in ("linear", "log") or ve.get("energy_quantization", "linear") not in ("linear", "log"):
+        raise ValueError("pitch_quantization / energy_quantization must be 'linear' or 'log' (reference U/layers.py:66,104)")
     vp = var["variance_predictor"]
     if vp["ffn_padding"] != "SAME":
         raise NotImplementedError("ffn_padding must be 'SAME'")
@@ -360,6 +367,9 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         block_type=1 if bt == "conformer" else 0,
         energy_layers=vp["ener_predictor_layers"], energy_kernel=vp["ener_predictor_kernel"],
         dec_n_head=tr["decoder_head"],
+        pitch_no_uv=0 if ve["use_uv"] else 1,
+        pitch_log2=1 if (ve["use_uv"] and ve["pitch_quantization"] == "log") else 0,   # (without uv the log / linear choice lives in the checkpoint's pitch_bins)
+        pitch_emb_rows=ve["n_bins"] if ve["use_uv"] else ve["f0_bins"],
         cf_ffn_factor=(0.5 if tr.get("half_step_residual", True) else 1.0),
     )
     if dims.ffn_k2 != 1:

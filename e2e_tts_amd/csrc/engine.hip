@@ -94,7 +94,7 @@ struct e2etts_engine {
   std::vector<CfLayer> cf_enc, cf_dec;  // cfg.block_type == 1
   Predictor dur, pitch, energy;
   const float *emb = nullptr, *enc_pos = nullptr, *dec_pos = nullptr, *pos_regen = nullptr, *spk_emb = nullptr;
-  const float *var_pos = nullptr, *pitch_emb = nullptr, *energy_emb = nullptr, *energy_bins = nullptr;
+  const float *var_pos = nullptr, *pitch_emb = nullptr, *energy_emb = nullptr, *energy_bins = nullptr, *pitch_bins = nullptr;
   uint64_t var_pos_rows = 0;
   ConvW mel_lin, voc_pre, voc_post;
   std::vector<ConvW> postnet, voc_up;
@@ -492,7 +492,7 @@ int bind_acoustic(e2etts_engine* e) {
     RET(bind_fft(e, "dec", c.dec_layers, e->dec));
   }
   RET(bind_pred(e, "dur", c.dur_layers, c.dur_kernel, c.dur_chans, 1, false, e->dur));
-  RET(bind_pred(e, "pitch", c.var_layers, c.var_kernel, c.var_chans, 2, true, e->pitch));
+  RET(bind_pred(e, "pitch", c.var_layers, c.var_kernel, c.var_chans, c.pitch_no_uv ? 1 : 2, true, e->pitch));
   RET(bind_pred(e, "energy", c.energy_layers ? c.energy_layers : c.var_layers, c.energy_kernel ? c.energy_kernel : c.var_kernel, c.var_chans, 1, true,
                 e->energy));
   {
@@ -502,7 +502,9 @@ int bind_acoustic(e2etts_engine* e) {
     e->var_pos = it->second.first;
     e->var_pos_rows = it->second.second / H;
   }
-  RET(get_tensor(e, "pitch.emb", (uint64_t)c.n_bins * H, &e->pitch_emb));
+  RET(get_tensor(e, "pitch.emb", (uint64_t)(c.pitch_emb_rows ? c.pitch_emb_rows : c.n_bins) * H, &e->pitch_emb));
+  e->pitch_bins = nullptr;
+  if (c.pitch_no_uv) RET(get_tensor(e, "pitch.bins", (uint64_t)c.n_bins - 1, &e->pitch_bins));
   RET(get_tensor(e, "energy.emb", (uint64_t)c.n_bins * H, &e->energy_emb));
   RET(get_tensor(e, "energy.bins", (uint64_t)c.n_bins - 1, &e->energy_bins));
   RET(get_tensor(e, "mel.w", (uint64_t)c.n_mel * H, &e->mel_lin.w));
@@ -925,7 +927,7 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_variance_embed(xs, ptr<float>(e->ppred), ptr<float>(e->epred), p_control, e_control, c.f0_mean, c.f0_std,
                                   e->energy_bins, c.n_bins, e->pitch_emb, e->energy_emb, ptr<int32_t>(e->pidx),
-                                  ptr<int32_t>(e->eidx), B, L, H, e->stream));
+                                  ptr<int32_t>(e->eidx), B, L, H, e->stream, c.pitch_no_uv ? 2 : (c.pitch_log2 ? 1 : 0), e->pitch_bins));
   }
   // the one host synchronisation of the acoustic model: T = max(mel_lens) sizes everything downstream
   HIPCHK(e, hipEventSynchronize(mel_ready));
@@ -1478,7 +1480,7 @@ int e2etts_acoustic(e2etts_engine* e, const int64_t* ids, const int64_t* lens, i
   if (pitch_idx_out) RET(copy_out(e, pitch_idx_out, e->pidx.p, BL * 4));
   if (energy_idx_out) RET(copy_out(e, energy_idx_out, e->eidx.p, BL * 4));
   if (log_dur_out) RET(copy_out(e, log_dur_out, e->logd.p, BL * 4));
-  if (pitch_pred_out) RET(copy_out(e, pitch_pred_out, e->ppred.p, BL * 8));
+  if (pitch_pred_out) RET(copy_out(e, pitch_pred_out, e->ppred.p, BL * (e->cfg.pitch_no_uv ? 4 : 8)));
   if (energy_pred_out) RET(copy_out(e, energy_pred_out, e->epred.p, BL * 4));
   if (T_out) *T_out = e->last_T;
   HIPCHK(e, hipStreamSynchronize(e->stream));

@@ -113,11 +113,13 @@ const char* launch_rowdot(const float* x, const float* w, const float* b, float*
 const char* launch_duration(const float* log_d, float d_control, float* dur, int32_t* cum, int64_t* mel_lens64,
                             int32_t* mel_lens32, int B, int L, hipStream_t s);
 // pitch / energy bucket indices + x += pitch_emb[pidx] + energy_emb[eidx]
-const char* launch_variance_embed(float* x, float* pitch_pred /*[B,L,2], scaled in place by p_control*/,
+// pitch_mode 0: f0 = pred[0] * std + mean, zeroed where pred[1] > 0 (uv), tensor_f0_to_coarse; 1: the same with f0 = 2 ** pred[0]
+// (pitch_quantization "log"); 2: use_uv False -- ONE prediction per row, bucketize(pred * p_control, pitch_bins) (U/layers.py:136-160)
+const char* launch_variance_embed(float* x, float* pitch_pred /*[B,L,2], scaled in place by p_control; mode 2: [B,L], left as it is*/,
                                   const float* energy_pred, float p_control, float e_control, float f0_mean,
                                   float f0_std, const float* energy_bins, int n_bins, const float* pitch_emb,
                                   const float* energy_emb, int32_t* pitch_idx, int32_t* energy_idx, int B, int L, int H,
-                                  hipStream_t s);
+                                  hipStream_t s, int pitch_mode = 0, const float* pitch_bins = nullptr);
 // length regulator fused with the decoder position add: y[b, t, :] = (t < mel_len[b] ? x[b, ph(t), :] : 0) + pos[t, :]
 const char* launch_length_regulate(const float* x, const int32_t* cum, const int32_t* mel_lens, const float* pos,
                                    float* y, int B, int L, int T, int H, hipStream_t s);

@@ -207,18 +207,31 @@ __global__ __launch_bounds__(128) void variance_embed_kernel(float* __restrict__
                                                              const float* __restrict__ energy_bins, int n_bins,
                                                              const float* __restrict__ pitch_emb, const float* __restrict__ energy_emb,
                                                              int32_t* __restrict__ pitch_idx, int32_t* __restrict__ energy_idx, int H,
-                                                             float mel_min, float mel_range) {
+                                                             float mel_min, float mel_range, int pitch_mode,
+                                                             const float* __restrict__ pitch_bins) {
   const int row = blockIdx.x;
-  const float f0 = __fmul_rn(pitch_pred[2 * row], p_control);
-  const float uvl = __fmul_rn(pitch_pred[2 * row + 1], p_control);
-  float f0d = __fadd_rn(__fmul_rn(f0, f0_std), f0_mean);
-  if (uvl > 0.f) f0d = 0.f;
-  float mel = __fmul_rn(1127.0f, logf(__fadd_rn(1.0f, __fdiv_rn(f0d, 700.0f))));
-  if (mel > 0.f) mel = __fadd_rn(__fdiv_rn(__fmul_rn(__fsub_rn(mel, mel_min), 254.0f), mel_range), 1.0f);
-  if (mel <= 1.f) mel = 1.f;
-  if (mel > 255.f) mel = 255.f;
-  int pidx = (int)__fadd_rn(mel, 0.5f);
-  pidx = pidx < 0 ? 0 : (pidx > n_bins - 1 ? n_bins - 1 : pidx);  // NaN guard only; the clamps above bound it
+  float f0, uvl = 0.f;
+  int pidx;
+  if (pitch_mode == 2) {  // use_uv False (U/layers.py:155-157): bucketize(prediction * control, pitch_bins), right = False
+    f0 = __fmul_rn(pitch_pred[row], p_control);
+    int lo = 0, hi = n_bins - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (pitch_bins[mid] < f0) lo = mid + 1; else hi = mid;
+    }
+    pidx = lo;
+  } else {
+    f0 = __fmul_rn(pitch_pred[2 * row], p_control);
+    uvl = __fmul_rn(pitch_pred[2 * row + 1], p_control);
+    float f0d = pitch_mode == 1 ? powf(2.0f, f0) : __fadd_rn(__fmul_rn(f0, f0_std), f0_mean);  // U/layers.py:148-151
+    if (uvl > 0.f) f0d = 0.f;
+    float mel = __fmul_rn(1127.0f, logf(__fadd_rn(1.0f, __fdiv_rn(f0d, 700.0f))));
+    if (mel > 0.f) mel = __fadd_rn(__fdiv_rn(__fmul_rn(__fsub_rn(mel, mel_min), 254.0f), mel_range), 1.0f);
+    if (mel <= 1.f) mel = 1.f;
+    if (mel > 255.f) mel = 255.f;
+    pidx = (int)__fadd_rn(mel, 0.5f);
+    pidx = pidx < 0 ? 0 : (pidx > n_bins - 1 ? n_bins - 1 : pidx);  // NaN guard only; the clamps above bound it
+  }
   const float e = __fmul_rn(energy_pred[row], e_control);
   int lo = 0, hi = n_bins - 1;  // first index with bins[idx] >= e; n_bins - 1 boundaries
   while (lo < hi) {
@@ -227,8 +240,10 @@ __global__ __launch_bounds__(128) void variance_embed_kernel(float* __restrict__
   }
   const int eidx = lo;
   if (threadIdx.x == 0) {
-    pitch_pred[2 * row] = f0;
-    pitch_pred[2 * row + 1] = uvl;
+    if (pitch_mode != 2) {  // (mode 2 hands back the prediction before the control, as the reference does: U/layers.py:156,162)
+      pitch_pred[2 * row] = f0;
+      pitch_pred[2 * row + 1] = uvl;
+    }
     pitch_idx[row] = pidx;
     energy_idx[row] = eidx;
   }
@@ -705,15 +720,16 @@ const char* launch_duration(const float* log_d, float d_control, float* dur, int
 const char* launch_variance_embed(float* x, float* pitch_pred, const float* energy_pred, float p_control, float e_control,
                                   float f0_mean, float f0_std, const float* energy_bins, int n_bins, const float* pitch_emb,
                                   const float* energy_emb, int32_t* pitch_idx, int32_t* energy_idx, int B, int L, int H,
-                                  hipStream_t s) {
+                                  hipStream_t s, int pitch_mode, const float* pitch_bins) {
   if (!x || !pitch_pred || !energy_pred || !energy_bins || !pitch_emb || !energy_emb || !pitch_idx || !energy_idx)
     return "variance_embed: null pointer";
+  if (pitch_mode < 0 || pitch_mode > 2 || (pitch_mode == 2 && !pitch_bins)) return "variance_embed: bad pitch mode";
   if (n_bins != 256) return "variance_embed: the f0 coarse coding is defined for 256 bins (reference U/function.py:9)";
   // f0_mel_min / max: numpy float64 constants, used by torch as fp32 scalars (U/function.py:12-13,180)
   const double mel_min = 1127.0 * log(1.0 + 50.0 / 700.0), mel_max = 1127.0 * log(1.0 + 1100.0 / 700.0);
   hipLaunchKernelGGL(variance_embed_kernel, dim3(B * L), dim3(128), 0, s, x, pitch_pred, energy_pred, p_control, e_control,
                      f0_mean, f0_std, energy_bins, n_bins, pitch_emb, energy_emb, pitch_idx, energy_idx, H, (float)mel_min,
-                     (float)(mel_max - mel_min));
+                     (float)(mel_max - mel_min), pitch_mode, pitch_bins);
   return CHECK_LAUNCH("variance_embed");
 }
 

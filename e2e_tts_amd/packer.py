@@ -244,7 +244,7 @@ def _pack_acoustic(dims: EngineDims, A, out) -> None:
     va = "variance_adaptor"
     for name, short, layers, kern, chans, odim in (
             ("duration_predictor", "dur", dims.dur_layers, dims.dur_kernel, dims.dur_chans, 1),
-            ("pitch_predictor", "pitch", dims.var_layers, dims.var_kernel, dims.var_chans, 2),
+            ("pitch_predictor", "pitch", dims.var_layers, dims.var_kernel, dims.var_chans, 1 if dims.pitch_no_uv else 2),
             ("energy_predictor", "energy", dims.energy_layers or dims.var_layers, dims.energy_kernel or dims.var_kernel, dims.var_chans, 1)):
         for i in range(layers):
             cin = H if i == 0 else chans
@@ -258,7 +258,9 @@ def _pack_acoustic(dims: EngineDims, A, out) -> None:
         if short != "dur":
             out[f"{short}.alpha"] = need(A, f"{va}.{name}.pos_embed_alpha", (1,))
     out["var.pos"] = variance_position_table(VAR_POS_INIT_ROWS, H)
-    out["pitch.emb"] = need(A, f"{va}.pitch_embedding.weight", (dims.n_bins, H))
+    out["pitch.emb"] = need(A, f"{va}.pitch_embedding.weight", (dims.pitch_emb_rows or dims.n_bins, H))
+    if dims.pitch_no_uv:
+        out["pitch.bins"] = need(A, f"{va}.pitch_bins", (dims.n_bins - 1,))
     out["energy.emb"] = need(A, f"{va}.energy_embedding.weight", (dims.n_bins, H))
     out["energy.bins"] = need(A, f"{va}.energy_bins", (dims.n_bins - 1,))
     out["mel.w"] = need(A, "mel_linear.weight", (dims.n_mel, H))

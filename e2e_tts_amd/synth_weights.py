@@ -134,7 +134,7 @@ def acoustic_manifest(config: dict, n_speakers: int, n_symbols: int = N_SYMBOLS)
     add(f"{va}.duration_predictor.linear.weight", (1, dc), "dur_w")
     add(f"{va}.duration_predictor.linear.bias", (1,), "dur_b")
     vc = vp["filter_size"]
-    for which, odim, layers, kern in (("pitch", 2, vp["pit_predictor_layers"], vp["pit_predictor_kernel"]),
+    for which, odim, layers, kern in (("pitch", 2 if ve["use_uv"] else 1, vp["pit_predictor_layers"], vp["pit_predictor_kernel"]),
                                       ("energy", 1, vp["ener_predictor_layers"], vp["ener_predictor_kernel"])):
         p = f"{va}.{which}_predictor"
         add(f"{p}.pos_embed_alpha", (1,), "alpha")
@@ -144,10 +144,12 @@ def acoustic_manifest(config: dict, n_speakers: int, n_symbols: int = N_SYMBOLS)
             add(f"{p}.conv.{i}.1.bias", (vc,), "b")
             add(f"{p}.conv.{i}.3.weight", (vc,), "gamma")
             add(f"{p}.conv.{i}.3.bias", (vc,), "beta")
+        pb = "pitch_b" if ve["use_uv"] and ve["pitch_quantization"] != "log" else ("pitch_b_log" if ve["use_uv"] else "pitch_b_nouv")
         add(f"{p}.linear.weight", (odim, vc), f"{which}_w")
-        add(f"{p}.linear.bias", (odim,), f"{which}_b")
+        add(f"{p}.linear.bias", (odim,), pb if which == "pitch" else f"{which}_b")
         add(f"{p}.embed_positions._float_tensor", (1,), "zero")
-        add(f"{va}.{which}_embedding.weight", (ve["n_bins"], H), "emb")
+        rows = ve["n_bins"] if (which == "energy" or ve["use_uv"]) else ve["f0_bins"]   # U/layers.py:60-63
+        add(f"{va}.{which}_embedding.weight", (rows, H), "emb")
     add("mel_linear.weight", (n_mel, H), "w")
     add("mel_linear.bias", (n_mel,), "b")
     P = pn["embedding_dim"]
@@ -252,9 +254,16 @@ def _draw(rng: np.random.Generator, name: str, shape: Shape, kind: str, *, stats
         b = (0.05 * rng.standard_normal(shape)).astype(f32)
         b[-1] -= 0.8  # bias the uv logit towards "voiced" so the f0 buckets are exercised
         return b
+    if kind == "pitch_b_log":   # f0 = 2 ** prediction: centre the f0 channel on log2(190 Hz)
+        b = (0.05 * rng.standard_normal(shape)).astype(f32)
+        b[0] += 7.57
+        b[-1] -= 0.8
+        return b
+    if kind == "pitch_b_nouv":  # one output bucketized on pitch_bins (stats "pitch" min .. max): centre it inside the range
+        return (4.0 + 0.05 * rng.standard_normal(shape)).astype(f32)
     if kind == "energy_b":
         return (2.5 + 0.05 * rng.standard_normal(shape)).astype(f32)
-    if kind == "pitch_bins":
+    if kind == "pitch_bins":   # (the reference's "log" variant needs positive stats; the synthetic ones are not: linear bins)
         return np.linspace(stats["pitch"]["min"], stats["pitch"]["max"], shape[0]).astype(f32)
     if kind == "energy_bins":
         return np.linspace(stats["energy"]["min"], stats["energy"]["max"], shape[0]).astype(f32)

@@ -84,6 +84,10 @@ typedef struct e2etts_config {
   int32_t energy_kernel;  /* predictor's (var_layers / var_kernel, U/layers.py:54,58), which is what the shipped model_config.yaml has */
   int32_t dec_n_head;     /* attention heads of the decoder's blocks (decoder_head, U/blocks/transformer.py:105, conformer.py:108); 0 = n_head, which then
                              is both encoder_head and decoder_head */
+  int32_t pitch_no_uv;    /* variance_embedding.use_uv == False (U/layers.py:136,155-157): the pitch predictor has ONE output, the bucket is
+                             torch.bucketize(prediction * p_control, pitch_bins) and the embedding table has pitch_emb_rows rows; 0 = use_uv */
+  int32_t pitch_log2;     /* with use_uv: pitch_quantization == "log" (U/layers.py:148-149): f0 = 2 ** prediction instead of prediction * std + mean */
+  int32_t pitch_emb_rows; /* rows of pitch_embedding (U/layers.py:60-63: n_bins with use_uv, f0_bins without); 0 = n_bins */
 } e2etts_config;
 
 /* Threading: every entry point takes the engine's internal mutex, so single calls are safe from any thread and distinct engines are
@@ -121,7 +125,7 @@ int e2etts_load_weights_bcast(e2etts_engine* engine, const void* blob_or_null, s
  *   n_spk_ids == 1 (broadcast, as API/utils.py:133 does) or == B.
  * Outputs (each may be NULL): dur [B, L] fp32 (duration_rounded), mel_lens [B] int64, T_out = max mel
  * length, pitch_idx / energy_idx [B, L] int32 (the bucket indices of U/function.py:178-187 and
- * U/layers.py:169), log_dur [B, L], pitch_pred [B, L, 2], energy_pred [B, L].
+ * U/layers.py:169), log_dur [B, L], pitch_pred [B, L, 2] ([B, L] when pitch_no_uv), energy_pred [B, L].
  * mel / mel_post stay resident; read them with e2etts_fetch_mel.  One host sync (for T). */
 int e2etts_acoustic(e2etts_engine* engine, const int64_t* ids, const int64_t* lens, int B, int L,
                     const int64_t* speaker, int n_spk_ids, float d_control, float p_control, float e_control,

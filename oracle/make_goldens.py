@@ -107,23 +107,30 @@ def run_reference(m, v, ids, lens, speaker, controls=(1.0, 1.0, 1.0), run_vocode
     return out
 
 
-def margins(out, energy_bins, stats, controls=(1.0, 1.0, 1.0), lens=None):
-    """Distance of every discrete decision to its rounding boundary (fp32 reference values)."""
+def margins(out, energy_bins, stats, controls=(1.0, 1.0, 1.0), lens=None, ve=None, pitch_bins=None):
+    """Distance of every discrete decision to its rounding boundary (fp32 reference values).  `ve`: the config's variance_embedding
+    section when it is not the shipped one (use_uv False: pitch bucketized on `pitch_bins`; pitch_quantization "log": f0 = 2 ** p)."""
     L = out["log_d"].shape[1]
     valid = np.arange(L)[None, :] < np.asarray(lens)[:, None]
     d = np.exp(out["log_d"].astype(np.float64)) - 1
     m_dur = np.abs((d - np.floor(d)) - 0.5)
     m_dur = np.where(valid, m_dur, 1.0)
     p = out["pitch_pred"].astype(np.float64)  # already multiplied by p_control (U/layers.py:147)
-    f0 = p[..., 0] * stats["f0"]["std"] + stats["f0"]["mean"]
-    uv = p[..., 1] > 0
-    m_uv = np.abs(p[..., 1])
-    mel = 1127 * np.log(1 + np.maximum(f0, -699.0) / 700)
-    b = np.where(mel > 0, (mel - orc.F0_MEL_MIN) * 254 / (orc.F0_MEL_MAX - orc.F0_MEL_MIN) + 1, mel)
-    # idx = trunc(clip(b, 1, 255) + 0.5) is continuous at both clip points and at mel == 0,
-    # so the only boundaries are the half-integers of b and the uv threshold.
-    fb = np.clip(b, 1, 255) + 0.5
-    m_f0 = np.where(uv, 1.0, np.minimum(fb - np.floor(fb), np.ceil(fb) - fb))
+    if ve is not None and not ve["use_uv"]:
+        pb = np.asarray(pitch_bins, np.float64)
+        p = p * controls[1]   # (this branch hands back the prediction BEFORE p_control, U/layers.py:156,162)
+        m_f0 = np.abs(p[..., None] - pb[None, None, :]).min(axis=-1) / float(pb[1] - pb[0])   # in bucket units
+        m_uv = np.ones_like(m_f0)
+    else:
+        f0 = np.power(2.0, p[..., 0]) if (ve is not None and ve["pitch_quantization"] == "log") else p[..., 0] * stats["f0"]["std"] + stats["f0"]["mean"]
+        uv = p[..., 1] > 0
+        m_uv = np.abs(p[..., 1])
+        mel = 1127 * np.log(1 + np.maximum(f0, -699.0) / 700)
+        b = np.where(mel > 0, (mel - orc.F0_MEL_MIN) * 254 / (orc.F0_MEL_MAX - orc.F0_MEL_MIN) + 1, mel)
+        # idx = trunc(clip(b, 1, 255) + 0.5) is continuous at both clip points and at mel == 0,
+        # so the only boundaries are the half-integers of b and the uv threshold.
+        fb = np.clip(b, 1, 255) + 0.5
+        m_f0 = np.where(uv, 1.0, np.minimum(fb - np.floor(fb), np.ceil(fb) - fb))
     m_f0 = np.where(valid, m_f0, 1.0)
     m_uv = np.where(valid, m_uv, 1.0)
     e = out["energy_pred"].astype(np.float64) * controls[2]
@@ -139,10 +146,12 @@ def oracle_margin(ac_oracle, ids, lens, speaker, stats, controls=(1.0, 1.0, 1.0)
     lens = np.asarray(lens, np.int64)
     pad = orc.get_mask_from_lengths(lens, ids.shape[1])
     x = ac_oracle.encoder(ids, pad) + ac_oracle.sd["speaker_emb.weight"][[speaker]][:, None, :]
+    ve = ac_oracle.fs["variance"]["variance_embedding"]
+    pp = ac_oracle.variance_predictor("pitch", x)
     out = dict(log_d=ac_oracle.duration_predictor(x, pad),
-               pitch_pred=ac_oracle.variance_predictor("pitch", x) * np.float32(controls[1]),
+               pitch_pred=pp * np.float32(controls[1]) if ve["use_uv"] else pp[..., 0],
                energy_pred=ac_oracle.variance_predictor("energy", x)[..., 0])
-    return margins(out, ac_oracle.sd["variance_adaptor.energy_bins"], stats, controls, lens)
+    return margins(out, ac_oracle.sd["variance_adaptor.energy_bins"], stats, controls, lens, ve, ac_oracle.sd["variance_adaptor.pitch_bins"])
 
 
 def make_ids(seed, lens, L=None):
@@ -201,7 +210,8 @@ def case_model(models, name, config, mode, lens, speaker, controls, ids_seed, wa
     seed, ids = search_ids(ac_or, lens, speaker, stats, controls, want_margin, max_tries, ids_seed, mode == "fixed")
     m, v = build_reference(models, config, stats, n_spk, ac_state, voc_state)
     out = run_reference(m, v, ids, lens, speaker, controls)
-    mg = margins(out, ac_state["variance_adaptor.energy_bins"], stats, controls, lens)
+    mg = margins(out, ac_state["variance_adaptor.energy_bins"], stats, controls, lens, config["models"]["fastspeech2"]["variance"]["variance_embedding"],
+                 ac_state["variance_adaptor.pitch_bins"])
     print(f"    reference margins {mg}; T={out['mel'].shape[1]} acoustic {out['t_acoustic_s']:.2f}s vocoder {out['t_vocoder_s']:.2f}s", flush=True)
     hop = config["audio"]["stft"]["hop_length"]
     meta = dict(ids=ids, lens=np.asarray(lens, np.int64), speaker=np.int64(speaker),
@@ -502,7 +512,8 @@ def case_bench_b32(models):
     seed, ids = best[1], best[2]
     m, v = build_reference(models, config, stats, n_spk, ac_state, voc_state)
     out = run_reference(m, v, ids, lens, speaker, controls)
-    mg = margins(out, ac_state["variance_adaptor.energy_bins"], stats, controls, lens)
+    mg = margins(out, ac_state["variance_adaptor.energy_bins"], stats, controls, lens, config["models"]["fastspeech2"]["variance"]["variance_embedding"],
+                 ac_state["variance_adaptor.pitch_bins"])
     print(f"    reference margins {mg}; T={out['mel'].shape[1]} acoustic {out['t_acoustic_s']:.2f}s vocoder {out['t_vocoder_s']:.2f}s", flush=True)
     hop = config["audio"]["stft"]["hop_length"]
     arrays = dict(ids=ids, lens=np.asarray(lens, np.int64), speaker=np.int64(speaker), controls=np.asarray(controls, np.float64),
@@ -555,6 +566,8 @@ def main():
         "full_cf_b2": lambda: case_model(models, "full_cf_b2", full_cf, "varied", [40, 27], 1, (1.0, 1.0, 1.0), 800, 1e-3, "medium"),
         "tiny_hv_b3": lambda: case_model(models, "tiny_hv_b3", tiny_hv, "varied", [21, 13, 30], 1, (1.0, 1.0, 1.0), 1100, 2e-3, "full"),
         "tiny_cf_hv_b3": lambda: case_model(models, "tiny_cf_hv_b3", tiny_cf_hv, "varied", [21, 13, 30], 2, (1.0, 1.0, 1.0), 1200, 2e-3, "full"),
+        "tiny_nouv_b3": lambda: case_model(models, "tiny_nouv_b3", pv_variant(cfgmod.tiny_config(), "nouv"), "varied", [19, 26, 8], 1, (1.0, 1.1, 0.9), 1300, 2e-3, "full"),
+        "tiny_plog_b3": lambda: case_model(models, "tiny_plog_b3", pv_variant(cfgmod.tiny_config(), "plog"), "varied", [19, 26, 8], 3, (1.0, 1.0, 1.0), 1400, 2e-3, "full"),
         "c1_plumbing": lambda: case_model(models, "c1_plumbing", full, "varied", [40], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
         "full_b3": lambda: case_model(models, "full_b3", full, "varied", [48, 31, 20], 1, (1.0, 1.0, 1.0), 500, 1e-3, "medium"),
     }
@@ -582,6 +595,17 @@ def hv_variant(cfg):
     bb["transformer"].update(encoder_head=2, decoder_head=1)     # hidden 64: head dims 32 / 64
     bb["conformer"].update(encoder_head=4, decoder_head=2)       # head dims 16 / 32
     fs["variance"]["variance_predictor"].update(ener_predictor_layers=3, ener_predictor_kernel=3)
+    return cfg
+
+
+def pv_variant(cfg, which):
+    """Fixtures `*_nouv_*` / `*_plog_*`: variance_embedding.use_uv False (one pitch output bucketized on pitch_bins, f0_bins embedding rows,
+    U/layers.py:60-63,136,155-157) and pitch_quantization "log" with use_uv (f0 = 2 ** prediction, U/layers.py:148-149)."""
+    ve = cfg["models"]["fastspeech2"]["variance"]["variance_embedding"]
+    if which == "nouv":
+        ve["use_uv"] = False
+    else:
+        ve["pitch_quantization"] = "log"
     return cfg
 
 

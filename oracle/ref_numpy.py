@@ -402,10 +402,18 @@ class AcousticOracle:
     # U/layers.py:136-162
     def pitch_embedding(self, x: np.ndarray, control: float) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         dt = self.dt
+        ve = self.fs["variance"]["variance_embedding"]
+        if not ve["use_uv"]:                                              # :138,155-157: squeeze, bucketize(prediction * control, pitch_bins);
+            pred = self.variance_predictor("pitch", x)[..., 0]            # the prediction handed back is the one BEFORE the control (:162)
+            idx = np.searchsorted(self.sd["variance_adaptor.pitch_bins"], pred * dt(control), side="left").astype(np.int64)
+            return pred, idx, self.sd["variance_adaptor.pitch_embedding.weight"][idx]
         pred = self.variance_predictor("pitch", x) * dt(control)
         f0 = pred[:, :, 0]
         uv = pred[:, :, 1] > 0
-        f0_denorm = f0 * dt(self.stats["f0"]["std"]) + dt(self.stats["f0"]["mean"])
+        if ve["pitch_quantization"] == "log":                             # :148-149
+            f0_denorm = np.power(dt(2), f0).astype(self.dt)
+        else:
+            f0_denorm = f0 * dt(self.stats["f0"]["std"]) + dt(self.stats["f0"]["mean"])
         f0_denorm = np.where(uv, dt(0), f0_denorm)
         idx = self.f0_to_coarse(f0_denorm)
         return pred, idx, self.sd["variance_adaptor.pitch_embedding.weight"][idx]

@@ -104,7 +104,9 @@ int main(int argc, char** argv) {
     Shape checks[] = {{"chk1", 2, 300, 80, 80, 5, 1, true, false, 0.1f}, {"chk2", 3, 777, 32, 32, 11, 5, true, true, 0.1f},
                       {"chk3", 1, 129, 128, 200, 3, 3, false, false, 1.0f}, {"chk4", 2, 64, 384, 1152, 1, 1, false, false, 1.0f},
                       {"chk5", 2, 1000, 64, 64, 7, 3, true, false, 0.1f}, {"chk6", 1, 50, 12, 20, 9, 1, false, false, 1.0f},
-                      {"chk7 odd", 2, 333, 32, 18, 7, 1, false, false, 1.0f}, {"chk8 odd", 1, 100, 64, 131, 3, 2, true, false, 0.1f}};  // Cout % 4 != 0: scalar epilogue
+                      {"chk7 odd", 2, 333, 32, 18, 7, 1, false, false, 1.0f}, {"chk8 odd", 1, 100, 64, 131, 3, 2, true, false, 0.1f},  // Cout % 4 != 0: scalar epilogue
+                      // enough 128 x 128 tiles for the persistent three-wave kernel (f32f): several tiles and chunks per workgroup, ragged last tile
+                      {"chk9 big", 8, 8200, 128, 128, 11, 5, true, false, 0.1f}, {"chk10 big", 8, 4100, 256, 256, 3, 1, true, true, 0.1f}};
     for (auto& c : checks) {
       size_t nin = (size_t)c.B * c.T * c.Cin, nout = (size_t)c.B * c.T * c.Cout, nw = (size_t)c.Cout * c.KW * c.Cin;
       std::vector<float> hin(nin), hw(nw), hb(c.Cout), hres(nout), hout0(nout);

@@ -200,6 +200,7 @@ class CEngineConfig(ctypes.Structure):
         ("pitch_no_uv", ctypes.c_int32),
         ("pitch_log2", ctypes.c_int32),
         ("pitch_emb_rows", ctypes.c_int32),
+        ("pred_pad_left", ctypes.c_int32),
     ]
 
 
@@ -245,6 +246,7 @@ class EngineDims:
     pitch_no_uv: int = 0      # variance_embedding.use_uv False: one pitch output, bucketize on pitch_bins, f0_bins embedding rows (U/layers.py:136-160)
     pitch_log2: int = 0       # use_uv with pitch_quantization "log": f0 = 2 ** prediction (U/layers.py:148-149)
     pitch_emb_rows: int = 0   # rows of pitch_embedding when not n_bins
+    pred_pad_left: int = 0    # variance_predictor.ffn_padding "LEFT": causal predictor convolutions (U/layers.py:400-402)
     cf_ffn_factor: float = 0.5  # Conformer half_step_residual (U/blocks/conformer.py:209-212); folded into the weights by the packer
     block_type: int = 0       # 0: FFT block (U/blocks/transformer.py), 1: Conformer block (U/blocks/conformer.py); then ffn_dim =
                               # hidden x ffn_expansion_factor and ffn_k1 = the depthwise kernel size
@@ -276,6 +278,7 @@ class EngineDims:
         c.energy_layers, c.energy_kernel = int(self.energy_layers), int(self.energy_kernel)
         c.dec_n_head = int(self.dec_n_head)
         c.pitch_no_uv, c.pitch_log2, c.pitch_emb_rows = int(self.pitch_no_uv), int(self.pitch_log2), int(self.pitch_emb_rows)
+        c.pred_pad_left = int(self.pred_pad_left)
         if len(self.voc_up_rate) > MAX_STAGES or len(self.voc_rb_kernel) > MAX_RESBLOCK_KERNELS:
             raise ValueError("vocoder config exceeds the C-ABI limits")
         c.voc_stages = len(self.voc_up_rate)
@@ -329,8 +332,6 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
     if ve["pitch_quantization"] not in ("linear", "log") or ve.get("energy_quantization", "linear") not in ("linear", "log"):
         raise ValueError("pitch_quantization / energy_quantization must be 'linear' or 'log' (reference U/layers.py:66,104)")
     vp = var["variance_predictor"]
-    if vp["ffn_padding"] != "SAME":
-        raise NotImplementedError("ffn_padding must be 'SAME'")
     # HifiGan picks ResBlock1 for `config['resblock'] == 1` (V/generator.py:19); iSTFT compares with the STRING '1'
     # (V/generator.py:71), so the shipped yaml (an int) gives it ResBlock2 -- reproduced, checkpoints depend on it
     rb1 = (hg["resblock"] == "1") if vocoder == "istft" else (hg["resblock"] == 1)
@@ -367,6 +368,7 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         block_type=1 if bt == "conformer" else 0,
         energy_layers=vp["ener_predictor_layers"], energy_kernel=vp["ener_predictor_kernel"],
         dec_n_head=tr["decoder_head"],
+        pred_pad_left=0 if vp["ffn_padding"] == "SAME" else 1,
         pitch_no_uv=0 if ve["use_uv"] else 1,
         pitch_log2=1 if (ve["use_uv"] and ve["pitch_quantization"] == "log") else 0,   # (without uv the log / linear choice lives in the checkpoint's pitch_bins)
         pitch_emb_rows=ve["n_bins"] if ve["use_uv"] else ve["f0_bins"],

@@ -752,7 +752,7 @@ int predictor(e2etts_engine* e, const Predictor& pr, const float* x, float* out,
     ConvParams p;
     p.B = B; p.T = L; p.in = in; p.w = l.w; p.bias = l.b; p.out = a; p.Cin = cin; p.Cout = pr.chans;
     p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;
-    p.KW = pr.kernel; p.pad = (pr.kernel - 1) / 2; p.act = ACT_RELU;
+    p.KW = pr.kernel; p.pad = e->cfg.pred_pad_left ? pr.kernel - 1 : (pr.kernel - 1) / 2; p.act = ACT_RELU;  // ConstantPad1d, U/layers.py:400-402
     RET(conv(e, p, 1.0, true));  // phoneme-level layer: conv_ksplit.hip at every batch size
     {
       ProfScope ps(e, "layernorm", 0, 8.0 * B * L * pr.chans);

@@ -88,6 +88,8 @@ typedef struct e2etts_config {
                              torch.bucketize(prediction * p_control, pitch_bins) and the embedding table has pitch_emb_rows rows; 0 = use_uv */
   int32_t pitch_log2;     /* with use_uv: pitch_quantization == "log" (U/layers.py:148-149): f0 = 2 ** prediction instead of prediction * std + mean */
   int32_t pitch_emb_rows; /* rows of pitch_embedding (U/layers.py:60-63: n_bins with use_uv, f0_bins without); 0 = n_bins */
+  int32_t pred_pad_left;  /* variance_predictor.ffn_padding != "SAME" (U/layers.py:400-402,479-481): the three predictors' convolutions are padded
+                             (k - 1, 0) -- causal -- instead of ((k - 1) / 2, (k - 1) / 2); 0 = SAME */
 } e2etts_config;
 
 /* Threading: every entry point takes the engine's internal mutex, so single calls are safe from any thread and distinct engines are

@@ -568,6 +568,7 @@ def main():
         "tiny_cf_hv_b3": lambda: case_model(models, "tiny_cf_hv_b3", tiny_cf_hv, "varied", [21, 13, 30], 2, (1.0, 1.0, 1.0), 1200, 2e-3, "full"),
         "tiny_nouv_b3": lambda: case_model(models, "tiny_nouv_b3", pv_variant(cfgmod.tiny_config(), "nouv"), "varied", [19, 26, 8], 1, (1.0, 1.1, 0.9), 1300, 2e-3, "full"),
         "tiny_plog_b3": lambda: case_model(models, "tiny_plog_b3", pv_variant(cfgmod.tiny_config(), "plog"), "varied", [19, 26, 8], 3, (1.0, 1.0, 1.0), 1400, 2e-3, "full"),
+        "tiny_lpad_b3": lambda: case_model(models, "tiny_lpad_b3", pv_variant(cfgmod.tiny_config(), "lpad"), "varied", [17, 28, 5], 2, (1.0, 1.0, 1.0), 1500, 2e-3, "full"),
         "c1_plumbing": lambda: case_model(models, "c1_plumbing", full, "varied", [40], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
         "full_b3": lambda: case_model(models, "full_b3", full, "varied", [48, 31, 20], 1, (1.0, 1.0, 1.0), 500, 1e-3, "medium"),
     }
@@ -604,8 +605,10 @@ def pv_variant(cfg, which):
     ve = cfg["models"]["fastspeech2"]["variance"]["variance_embedding"]
     if which == "nouv":
         ve["use_uv"] = False
-    else:
+    elif which == "plog":
         ve["pitch_quantization"] = "log"
+    else:   # "lpad": variance_predictor.ffn_padding "LEFT" -- causal predictor convolutions (U/layers.py:400-402,479-481)
+        cfg["models"]["fastspeech2"]["variance"]["variance_predictor"]["ffn_padding"] = "LEFT"
     return cfg
 
 

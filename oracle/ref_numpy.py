@@ -354,6 +354,14 @@ class AcousticOracle:
             x = self.block(f"decoder.layer_stack.{l}", x, pad)
         return x
 
+    # ConstantPad1d in front of every predictor convolution (U/layers.py:400-402, :479-481): ((k-1)//2, (k-1)//2) for ffn_padding "SAME",
+    # (k - 1, 0) -- causal -- otherwise
+    def _pred_conv(self, xs: np.ndarray, w: np.ndarray, b: np.ndarray, k: int) -> np.ndarray:
+        if self.fs["variance"]["variance_predictor"]["ffn_padding"] == "SAME":
+            return conv1d(xs, w, b, padding=(k - 1) // 2)
+        xp = np.concatenate([np.zeros(xs.shape[:2] + (k - 1,), xs.dtype), xs], axis=2)
+        return conv1d(xp, w, b, padding=0)
+
     # U/layers.py:410-420 (ctor :382-408); channel LayerNorm eps 1e-12: U/sublayers.py:151-170
     def duration_predictor(self, x: np.ndarray, pad: np.ndarray) -> np.ndarray:
         sd, p = self.sd, "variance_adaptor.duration_predictor"
@@ -361,7 +369,7 @@ class AcousticOracle:
         xs = x.transpose(0, 2, 1)
         for i in range(self.fs["variance"]["variance_predictor"]["dur_predictor_layers"]):
             k = sd[f"{p}.conv.{i}.1.weight"].shape[2]
-            xs = conv1d(xs, sd[f"{p}.conv.{i}.1.weight"], sd[f"{p}.conv.{i}.1.bias"], padding=(k - 1) // 2)
+            xs = self._pred_conv(xs, sd[f"{p}.conv.{i}.1.weight"], sd[f"{p}.conv.{i}.1.bias"], k)
             xs = np.maximum(xs, 0)
             xs = layer_norm(xs.transpose(0, 2, 1), sd[f"{p}.conv.{i}.3.weight"], sd[f"{p}.conv.{i}.3.bias"], 1e-12).transpose(0, 2, 1)
             xs = xs * keep[:, None, :]
@@ -383,7 +391,7 @@ class AcousticOracle:
         n_layers = self.fs["variance"]["variance_predictor"]["pit_predictor_layers" if which == "pitch" else "ener_predictor_layers"]
         for i in range(n_layers):
             k = sd[f"{p}.conv.{i}.1.weight"].shape[2]
-            xs = conv1d(xs, sd[f"{p}.conv.{i}.1.weight"], sd[f"{p}.conv.{i}.1.bias"], padding=(k - 1) // 2)
+            xs = self._pred_conv(xs, sd[f"{p}.conv.{i}.1.weight"], sd[f"{p}.conv.{i}.1.bias"], k)
             xs = np.maximum(xs, 0)
             xs = layer_norm(xs.transpose(0, 2, 1), sd[f"{p}.conv.{i}.3.weight"], sd[f"{p}.conv.{i}.3.bias"], 1e-12).transpose(0, 2, 1)
         return linear(xs.transpose(0, 2, 1), sd[p + ".linear.weight"], sd[p + ".linear.bias"])

@@ -61,6 +61,8 @@ def load_library() -> C.CDLL:
     lib.e2etts_fetch_mel.argtypes = [P, P, P]
     lib.e2etts_fetch_tap.restype = I
     lib.e2etts_fetch_tap.argtypes = [P, C.c_char_p, P, SZ]
+    lib.e2etts_fetch_tap_i32.restype = I
+    lib.e2etts_fetch_tap_i32.argtypes = [P, C.c_char_p, P, SZ]
     lib.e2etts_vocoder.restype = I
     lib.e2etts_vocoder.argtypes = [P, P, I, I, P, P]
     lib.e2etts_vocoder_btc.restype = I
@@ -105,7 +107,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "e2etts_version", "e2etts_last_error", "e2etts_create", "e2etts_destroy", "e2etts_load_weights", "e2etts_acoustic",
-    "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
+    "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_fetch_tap_i32", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
     "e2etts_fetch_wav", "e2etts_vocoder_stream_begin", "e2etts_vocoder_stream_push", "e2etts_vocoder_stream_fetch",
     "e2etts_set_precision", "e2etts_set_ragged", "e2etts_debug_poison_workspace", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_filter", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
     "e2etts_load_weights_bcast", "e2etts_order_after", "e2etts_tempo",
@@ -249,14 +251,15 @@ class Engine:
             raise ValueError(f"speaker holds {n_spk} ids, expected 1 or {B}")
         self._order(ids, lens, speaker)
         out = {}
+        pf, ef = bool(self.dims.pitch_frame), bool(self.dims.energy_frame)   # frame_level features: T columns, fetched after the call (below)
         bufs = dict(
             dur=np.empty((B, L), np.float32) if "dur" in want else None,
             mel_lens=np.empty((B,), np.int64) if "mel_lens" in want else None,
-            pitch_idx=np.empty((B, L), np.int32) if "pitch_idx" in want else None,
-            energy_idx=np.empty((B, L), np.int32) if "energy_idx" in want else None,
+            pitch_idx=np.empty((B, L), np.int32) if "pitch_idx" in want and not pf else None,
+            energy_idx=np.empty((B, L), np.int32) if "energy_idx" in want and not ef else None,
             log_d=np.empty((B, L), np.float32) if "log_d" in want else None,
-            pitch_pred=np.empty((B, L) if self.dims.pitch_no_uv else (B, L, 2), np.float32) if "pitch_pred" in want else None,
-            energy_pred=np.empty((B, L), np.float32) if "energy_pred" in want else None,
+            pitch_pred=np.empty((B, L) if self.dims.pitch_no_uv else (B, L, 2), np.float32) if "pitch_pred" in want and not pf else None,
+            energy_pred=np.empty((B, L), np.float32) if "energy_pred" in want and not ef else None,
         )
         T = C.c_int(0)
         rc = self.lib.e2etts_acoustic(self._h, _addr(ids), _addr(lens), B, L, _addr(speaker), n_spk,
@@ -268,6 +271,14 @@ class Engine:
         out.update({k: v for k, v in bufs.items() if v is not None})
         out["T"] = T.value
         out["B"] = B
+        for name, frame, shape, dt in (("pitch_idx", pf, (B, T.value), np.int32), ("energy_idx", ef, (B, T.value), np.int32),
+                                       ("pitch_pred", pf, (B, T.value) if self.dims.pitch_no_uv else (B, T.value, 2), np.float32),
+                                       ("energy_pred", ef, (B, T.value), np.float32)):
+            if frame and name in want:
+                a = np.empty(shape, dt)
+                fn = self.lib.e2etts_fetch_tap_i32 if dt is np.int32 else self.lib.e2etts_fetch_tap
+                self._check(fn(self._h, name.encode(), _addr(a), a.size), "e2etts_fetch_tap")
+                out[name] = a
         return out
 
     @_locked

@@ -201,6 +201,8 @@ class CEngineConfig(ctypes.Structure):
         ("pitch_log2", ctypes.c_int32),
         ("pitch_emb_rows", ctypes.c_int32),
         ("pred_pad_left", ctypes.c_int32),
+        ("pitch_frame", ctypes.c_int32),
+        ("energy_frame", ctypes.c_int32),
     ]
 
 
@@ -247,6 +249,8 @@ class EngineDims:
     pitch_log2: int = 0       # use_uv with pitch_quantization "log": f0 = 2 ** prediction (U/layers.py:148-149)
     pitch_emb_rows: int = 0   # rows of pitch_embedding when not n_bins
     pred_pad_left: int = 0    # variance_predictor.ffn_padding "LEFT": causal predictor convolutions (U/layers.py:400-402)
+    pitch_frame: int = 0      # variance_embedding.pitch_feature / energy_feature "frame_level": predictor + embedding on the length regulator's
+    energy_frame: int = 0     # output instead of on the phonemes (U/layers.py:226-257)
     cf_ffn_factor: float = 0.5  # Conformer half_step_residual (U/blocks/conformer.py:209-212); folded into the weights by the packer
     block_type: int = 0       # 0: FFT block (U/blocks/transformer.py), 1: Conformer block (U/blocks/conformer.py); then ffn_dim =
                               # hidden x ffn_expansion_factor and ffn_k1 = the depthwise kernel size
@@ -279,6 +283,7 @@ class EngineDims:
         c.dec_n_head = int(self.dec_n_head)
         c.pitch_no_uv, c.pitch_log2, c.pitch_emb_rows = int(self.pitch_no_uv), int(self.pitch_log2), int(self.pitch_emb_rows)
         c.pred_pad_left = int(self.pred_pad_left)
+        c.pitch_frame, c.energy_frame = int(self.pitch_frame), int(self.energy_frame)
         if len(self.voc_up_rate) > MAX_STAGES or len(self.voc_rb_kernel) > MAX_RESBLOCK_KERNELS:
             raise ValueError("vocoder config exceeds the C-ABI limits")
         c.voc_stages = len(self.voc_up_rate)
@@ -327,8 +332,9 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
     if not var["duration_modelling"]["learn_alignment"]:
         raise NotImplementedError("SupervisedFastSpeech2 is out of scope (reference API/utils.py:37-40)")
     ve = var["variance_embedding"]
-    if ve["pitch_feature"] != "phoneme_level" or ve["energy_feature"] != "phoneme_level":
-        raise NotImplementedError("only phoneme-level pitch/energy are implemented (reference U/layers.py:226-239; frame level: :249-257)")
+    for k in ("pitch_feature", "energy_feature"):
+        if ve[k] not in ("phoneme_level", "frame_level"):
+            raise ValueError(f"{k} must be 'phoneme_level' or 'frame_level' (reference U/layers.py:48,88)")
     if ve["pitch_quantization"] not in ("linear", "log") or ve.get("energy_quantization", "linear") not in ("linear", "log"):
         raise ValueError("pitch_quantization / energy_quantization must be 'linear' or 'log' (reference U/layers.py:66,104)")
     vp = var["variance_predictor"]
@@ -369,6 +375,7 @@ def dims_from_config(config: dict, stats: dict, n_speakers: int, n_symbols: int 
         energy_layers=vp["ener_predictor_layers"], energy_kernel=vp["ener_predictor_kernel"],
         dec_n_head=tr["decoder_head"],
         pred_pad_left=0 if vp["ffn_padding"] == "SAME" else 1,
+        pitch_frame=1 if ve["pitch_feature"] == "frame_level" else 0, energy_frame=1 if ve["energy_feature"] == "frame_level" else 0,
         pitch_no_uv=0 if ve["use_uv"] else 1,
         pitch_log2=1 if (ve["use_uv"] and ve["pitch_quantization"] == "log") else 0,   # (without uv the log / linear choice lives in the checkpoint's pitch_bins)
         pitch_emb_rows=ve["n_bins"] if ve["use_uv"] else ve["f0_bins"],

@@ -742,7 +742,7 @@ int conformer_stack(e2etts_engine* e, const std::vector<CfLayer>& layers, int n_
 // conv -> ReLU -> channel LayerNorm(eps 1e-12) [-> x (1 - mask)] stack + small Linear
 // (reference DurationPredictor U/layers.py:410-420, VariancePredictor :499-503)
 int predictor(e2etts_engine* e, const Predictor& pr, const float* x, float* out, const int32_t* mask_lens, int B, int L,
-              const int32_t* act = nullptr, const int32_t* act_host = nullptr, double act_frac = 1.0) {
+              const int32_t* act = nullptr, const int32_t* act_host = nullptr, double act_frac = 1.0, bool frame_level = false) {
   const int H = e->cfg.hidden;
   float* a = ptr<float>(e->p1);  // conv output
   float* b = ptr<float>(e->p2);  // LayerNorm output = next layer's input
@@ -753,7 +753,7 @@ int predictor(e2etts_engine* e, const Predictor& pr, const float* x, float* out,
     p.B = B; p.T = L; p.in = in; p.w = l.w; p.bias = l.b; p.out = a; p.Cin = cin; p.Cout = pr.chans;
     p.act_rows = act; p.act_rows_host = act_host; p.act_frac = act_frac;
     p.KW = pr.kernel; p.pad = e->cfg.pred_pad_left ? pr.kernel - 1 : (pr.kernel - 1) / 2; p.act = ACT_RELU;  // ConstantPad1d, U/layers.py:400-402
-    RET(conv(e, p, 1.0, true));  // phoneme-level layer: conv_ksplit.hip at every batch size
+    RET(conv(e, p, 1.0, !frame_level));  // phoneme-level layer: conv_ksplit.hip at every batch size; frame-level (B x T rows): conv_gemm at every batch size
     {
       ProfScope ps(e, "layernorm", 0, 8.0 * B * L * pr.chans);
       KCHK(e, launch_layernorm(a, b, l.g, l.beta, mask_lens, B, L, pr.chans, 1e-12f, e->stream));
@@ -912,22 +912,28 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   HIPCHK(e, hipEventRecord(mel_ready, e->stream));
   // pitch / energy predictors run while the mel lengths travel to the host
   float* xp = ptr<float>(e->xp);
-  {
-    ProfScope ps(e, "misc", 0, 0);
-    KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->pitch.alpha, xp, B, L, H, e->stream));
+  const bool p_frame = c.pitch_frame != 0, e_frame = c.energy_frame != 0;   // frame_level features wait for the length regulator (below)
+  const int pitch_mode = c.pitch_no_uv ? 2 : (c.pitch_log2 ? 1 : 0);
+  if (!p_frame) {
+    {
+      ProfScope ps(e, "misc", 0, 0);
+      KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->pitch.alpha, xp, B, L, H, e->stream));
+    }
+    RET(predictor(e, e->pitch, xp, ptr<float>(e->ppred), nullptr, B, L, act_var, act_var_h, frac_var));
   }
-  RET(predictor(e, e->pitch, xp, ptr<float>(e->ppred), nullptr, B, L, act_var, act_var_h, frac_var));
-  {
-    ProfScope ps(e, "misc", 0, 0);
-    KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->energy.alpha, xp, B, L, H, e->stream,
-                                 false));  // the positions depend on xs alone: the pitch predictor's pass left them in posbuf
+  if (!e_frame) {
+    {
+      ProfScope ps(e, "misc", 0, 0);
+      KCHK(e, launch_var_positions(xs, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->energy.alpha, xp, B, L, H, e->stream,
+                                   p_frame));  // the positions depend on xs alone: the pitch predictor's pass (if it ran) left them in posbuf
+    }
+    RET(predictor(e, e->energy, xp, ptr<float>(e->epred), nullptr, B, L, act_var, act_var_h, frac_var));
   }
-  RET(predictor(e, e->energy, xp, ptr<float>(e->epred), nullptr, B, L, act_var, act_var_h, frac_var));
-  {
+  if (!p_frame || !e_frame) {
     ProfScope ps(e, "misc", 0, 0);
     KCHK(e, launch_variance_embed(xs, ptr<float>(e->ppred), ptr<float>(e->epred), p_control, e_control, c.f0_mean, c.f0_std,
                                   e->energy_bins, c.n_bins, e->pitch_emb, e->energy_emb, ptr<int32_t>(e->pidx),
-                                  ptr<int32_t>(e->eidx), B, L, H, e->stream, c.pitch_no_uv ? 2 : (c.pitch_log2 ? 1 : 0), e->pitch_bins));
+                                  ptr<int32_t>(e->eidx), B, L, H, e->stream, pitch_mode, e->pitch_bins, (p_frame ? 0 : 1) | (e_frame ? 0 : 2)));
   }
   // the one host synchronisation of the acoustic model: T = max(mel_lens) sizes everything downstream
   HIPCHK(e, hipEventSynchronize(mel_ready));
@@ -956,7 +962,40 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
   const int32_t* ml = ptr<int32_t>(e->mel32);
   {
     ProfScope ps(e, "misc", 0, 0);
-    KCHK(e, launch_length_regulate(xs, ptr<int32_t>(e->cum), ml, dpos, dx, B, L, (int)T, H, e->stream));
+    KCHK(e, launch_length_regulate(xs, ptr<int32_t>(e->cum), ml, (p_frame || e_frame) ? nullptr : dpos, dx, B, L, (int)T, H, e->stream));
+  }
+  if (p_frame || e_frame) {
+    // frame_level pitch / energy (U/layers.py:249-257): both predictors read the length regulator's output, their embeddings are added
+    // to it -- on every row, padded ones included, as the reference does; the decoder masks those -- and the decoder's positions follow
+    if (T + 1 > (long long)e->var_pos_rows)
+      return e->fail(E2ETTS_EINVAL, "T=%lld exceeds the variance predictors' position table (%lld rows)", T, (long long)e->var_pos_rows);
+    const size_t pcw = (size_t)std::max(c.dur_chans, c.var_chans);
+    RET(ensure(e, e->p1, BT * pcw * 4));
+    RET(ensure(e, e->p2, BT * pcw * 4));
+    RET(ensure(e, e->posbuf, BT * 4));
+    if (p_frame) { RET(ensure(e, e->ppred, BT * 2 * 4)); RET(ensure(e, e->pidx, BT * 4)); }
+    if (e_frame) { RET(ensure(e, e->epred, BT * 4)); RET(ensure(e, e->eidx, BT * 4)); }
+    float* xpf = ptr<float>(e->dxb);   // [B, T, H]: free until the decoder starts
+    if (p_frame) {
+      {
+        ProfScope ps(e, "misc", 0, 0);
+        KCHK(e, launch_var_positions(dx, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->pitch.alpha, xpf, B, (int)T, H, e->stream));
+      }
+      RET(predictor(e, e->pitch, xpf, ptr<float>(e->ppred), nullptr, B, (int)T, nullptr, nullptr, 1.0, true));
+    }
+    if (e_frame) {
+      {
+        ProfScope ps(e, "misc", 0, 0);
+        KCHK(e, launch_var_positions(dx, ptr<int32_t>(e->posbuf), e->var_pos, (int)e->var_pos_rows, e->energy.alpha, xpf, B, (int)T, H, e->stream,
+                                     !p_frame));
+      }
+      RET(predictor(e, e->energy, xpf, ptr<float>(e->epred), nullptr, B, (int)T, nullptr, nullptr, 1.0, true));
+    }
+    ProfScope ps(e, "misc", 0, 0);
+    KCHK(e, launch_variance_embed(dx, ptr<float>(e->ppred), ptr<float>(e->epred), p_control, e_control, c.f0_mean, c.f0_std,
+                                  e->energy_bins, c.n_bins, e->pitch_emb, e->energy_emb, ptr<int32_t>(e->pidx),
+                                  ptr<int32_t>(e->eidx), B, (int)T, H, e->stream, pitch_mode, e->pitch_bins, (p_frame ? 1 : 0) | (e_frame ? 2 : 0)));
+    KCHK(e, launch_add_positions(dx, dpos, B, (int)T, H, e->stream));
   }
   // Ragged mode (synthesize only).  Decoder: every consumer of a row >= mel_len masks it (keys are masked, the LayerNorm
   // kernels write zeros there), so its convolutions compute rows < mel_len only and valid rows stay bit-identical.
@@ -1477,6 +1516,8 @@ int e2etts_acoustic(e2etts_engine* e, const int64_t* ids, const int64_t* lens, i
   const size_t BL = (size_t)B * L;
   if (dur_out) RET(copy_out(e, dur_out, e->durf.p, BL * 4));
   if (mel_lens_out) RET(copy_out(e, mel_lens_out, e->mel64.p, (size_t)B * 8));
+  if ((e->cfg.pitch_frame && (pitch_idx_out || pitch_pred_out)) || (e->cfg.energy_frame && (energy_idx_out || energy_pred_out)))
+    return e->fail(E2ETTS_EINVAL, "a frame_level feature's index / prediction has T columns: pass NULL here and read it with e2etts_fetch_tap[_i32]");
   if (pitch_idx_out) RET(copy_out(e, pitch_idx_out, e->pidx.p, BL * 4));
   if (energy_idx_out) RET(copy_out(e, energy_idx_out, e->eidx.p, BL * 4));
   if (log_dur_out) RET(copy_out(e, log_dur_out, e->logd.p, BL * 4));
@@ -1514,10 +1555,29 @@ int e2etts_fetch_tap(e2etts_engine* e, const char* which, float* out, size_t n_f
     return E2ETTS_OK;
   }
   if (!e->have_acoustic) return e->fail(E2ETTS_ESTATE, "no acoustic result resident");
-  if (!strcmp(which, "enc_out")) { src = e->xa.p;  /* the encoder's output stays in its own buffer: nothing later in the pass writes it */ n = (size_t)e->last_B * e->last_L * e->cfg.hidden; }
+  const size_t np = (size_t)e->last_B * (e->cfg.pitch_frame ? e->last_T : e->last_L), ne = (size_t)e->last_B * (e->cfg.energy_frame ? e->last_T : e->last_L);
+  if (!strcmp(which, "pitch_pred")) { src = e->ppred.p; n = np * (e->cfg.pitch_no_uv ? 1 : 2); }
+  else if (!strcmp(which, "energy_pred")) { src = e->epred.p; n = ne; }
+  else if (!strcmp(which, "enc_out")) { src = e->xa.p;  /* the encoder's output stays in its own buffer: nothing later in the pass writes it */ n = (size_t)e->last_B * e->last_L * e->cfg.hidden; }
   else if (!strcmp(which, "dec_out")) { src = e->dx.p; n = (size_t)e->last_B * e->last_T * e->cfg.hidden; }
   else return e->fail(E2ETTS_EKEY, "unknown tap '%s'", which);
   if (n_floats != n) return e->fail(E2ETTS_EINVAL, "tap '%s' holds %zu floats, caller asked for %zu", which, n, n_floats);
+  RET(copy_out(e, out, src, n * 4));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return E2ETTS_OK;
+}
+
+int e2etts_fetch_tap_i32(e2etts_engine* e, const char* which, int32_t* out, size_t n_values) {
+  if (!e || !which || !out) return E2ETTS_EINVAL;
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->have_acoustic) return e->fail(E2ETTS_ESTATE, "no acoustic result resident");
+  const void* src = nullptr;
+  size_t n = 0;
+  if (!strcmp(which, "pitch_idx")) { src = e->pidx.p; n = (size_t)e->last_B * (e->cfg.pitch_frame ? e->last_T : e->last_L); }
+  else if (!strcmp(which, "energy_idx")) { src = e->eidx.p; n = (size_t)e->last_B * (e->cfg.energy_frame ? e->last_T : e->last_L); }
+  else return e->fail(E2ETTS_EKEY, "unknown tap '%s'", which);
+  if (n_values != n) return e->fail(E2ETTS_EINVAL, "tap '%s' holds %zu values, caller asked for %zu", which, n, n_values);
   RET(copy_out(e, out, src, n * 4));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return E2ETTS_OK;

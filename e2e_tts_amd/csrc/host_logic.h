@@ -110,8 +110,9 @@ inline const char* config_check(const e2etts_config& c) {
   }
   if (c.n_bins != 256) return "n_bins must be 256";
   if (c.pitch_emb_rows != 0 && !in(c.pitch_emb_rows, c.n_bins, BIG)) return "pitch_emb_rows must cover n_bins";
-  if ((c.pitch_no_uv != 0 && c.pitch_no_uv != 1) || (c.pitch_log2 != 0 && c.pitch_log2 != 1) || (c.pred_pad_left != 0 && c.pred_pad_left != 1))
-    return "pitch_no_uv / pitch_log2 / pred_pad_left must be 0 or 1";
+  if ((c.pitch_no_uv != 0 && c.pitch_no_uv != 1) || (c.pitch_log2 != 0 && c.pitch_log2 != 1) || (c.pred_pad_left != 0 && c.pred_pad_left != 1) ||
+      (c.pitch_frame != 0 && c.pitch_frame != 1) || (c.energy_frame != 0 && c.energy_frame != 1))
+    return "pitch_no_uv / pitch_log2 / pred_pad_left / pitch_frame / energy_frame must be 0 or 1";
   if (!in(c.max_seq_len, 1, BIG) || !in(c.pos_table_rows, c.max_seq_len + 1, 1 << 24)) return "pos_table_rows must cover max_seq_len + 1";
   if (!in(c.hop_length, 1, BIG) || !in(c.sample_rate, 1, 1 << 24)) return "hop_length and sample_rate must be positive";
   return nullptr;

@@ -119,8 +119,10 @@ const char* launch_variance_embed(float* x, float* pitch_pred /*[B,L,2], scaled 
                                   const float* energy_pred, float p_control, float e_control, float f0_mean,
                                   float f0_std, const float* energy_bins, int n_bins, const float* pitch_emb,
                                   const float* energy_emb, int32_t* pitch_idx, int32_t* energy_idx, int B, int L, int H,
-                                  hipStream_t s, int pitch_mode = 0, const float* pitch_bins = nullptr);
-// length regulator fused with the decoder position add: y[b, t, :] = (t < mel_len[b] ? x[b, ph(t), :] : 0) + pos[t, :]
+                                  hipStream_t s, int pitch_mode = 0, const float* pitch_bins = nullptr, int feat = 3 /* bit 0 pitch, bit 1 energy */);
+// y[b, t, :] += pos[t, :]
+const char* launch_add_positions(float* y, const float* pos, int B, int T, int H, hipStream_t s);
+// length regulator fused with the decoder position add: y[b, t, :] = (t < mel_len[b] ? x[b, ph(t), :] : 0) + pos[t, :] (pos == nullptr: without it)
 const char* launch_length_regulate(const float* x, const int32_t* cum, const int32_t* mel_lens, const float* pos,
                                    float* y, int B, int L, int T, int H, hipStream_t s);
 // out[b] = min(cap, (lens[b] + add) * mul + add_rows): rows a layer has to compute for utterance b in ragged mode

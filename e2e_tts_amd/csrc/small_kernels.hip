@@ -208,11 +208,13 @@ __global__ __launch_bounds__(128) void variance_embed_kernel(float* __restrict__
                                                              const float* __restrict__ pitch_emb, const float* __restrict__ energy_emb,
                                                              int32_t* __restrict__ pitch_idx, int32_t* __restrict__ energy_idx, int H,
                                                              float mel_min, float mel_range, int pitch_mode,
-                                                             const float* __restrict__ pitch_bins) {
+                                                             const float* __restrict__ pitch_bins, int feat) {
   const int row = blockIdx.x;
-  float f0, uvl = 0.f;
-  int pidx;
-  if (pitch_mode == 2) {  // use_uv False (U/layers.py:155-157): bucketize(prediction * control, pitch_bins), right = False
+  float f0 = 0.f, uvl = 0.f;
+  int pidx = 0;
+  // feat: bit 0 = pitch, bit 1 = energy take part in this pass (the other one lives at the other level: phoneme / frame, U/layers.py:226-257)
+  if (!(feat & 1)) {
+  } else if (pitch_mode == 2) {  // use_uv False (U/layers.py:155-157): bucketize(prediction * control, pitch_bins), right = False
     f0 = __fmul_rn(pitch_pred[row], p_control);
     int lo = 0, hi = n_bins - 1;
     while (lo < hi) {
@@ -232,27 +234,38 @@ __global__ __launch_bounds__(128) void variance_embed_kernel(float* __restrict__
     pidx = (int)__fadd_rn(mel, 0.5f);
     pidx = pidx < 0 ? 0 : (pidx > n_bins - 1 ? n_bins - 1 : pidx);  // NaN guard only; the clamps above bound it
   }
-  const float e = __fmul_rn(energy_pred[row], e_control);
-  int lo = 0, hi = n_bins - 1;  // first index with bins[idx] >= e; n_bins - 1 boundaries
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (energy_bins[mid] < e) lo = mid + 1; else hi = mid;
+  int eidx = 0;
+  if (feat & 2) {
+    const float e = __fmul_rn(energy_pred[row], e_control);
+    int lo = 0, hi = n_bins - 1;  // first index with bins[idx] >= e; n_bins - 1 boundaries
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (energy_bins[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    eidx = lo;
   }
-  const int eidx = lo;
   if (threadIdx.x == 0) {
-    if (pitch_mode != 2) {  // (mode 2 hands back the prediction before the control, as the reference does: U/layers.py:156,162)
+    if ((feat & 1) && pitch_mode != 2) {  // (mode 2 hands back the prediction before the control, as the reference does: U/layers.py:156,162)
       pitch_pred[2 * row] = f0;
       pitch_pred[2 * row + 1] = uvl;
     }
-    pitch_idx[row] = pidx;
-    energy_idx[row] = eidx;
+    if (feat & 1) pitch_idx[row] = pidx;
+    if (feat & 2) energy_idx[row] = eidx;
   }
   float4* xr = reinterpret_cast<float4*>(x + (long long)row * H);
   const float4* pe = reinterpret_cast<const float4*>(pitch_emb + (long long)pidx * H);
   const float4* ee = reinterpret_cast<const float4*>(energy_emb + (long long)eidx * H);
-  for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
-    const float4 a = xr[i], p = pe[i], q = ee[i];
-    xr[i] = make_float4((a.x + p.x) + q.x, (a.y + p.y) + q.y, (a.z + p.z) + q.z, (a.w + p.w) + q.w);
+  if (feat == 3) {
+    for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
+      const float4 a = xr[i], p = pe[i], q = ee[i];
+      xr[i] = make_float4((a.x + p.x) + q.x, (a.y + p.y) + q.y, (a.z + p.z) + q.z, (a.w + p.w) + q.w);
+    }
+  } else {
+    const float4* oe = (feat & 1) ? pe : ee;
+    for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
+      const float4 a = xr[i], p = oe[i];
+      xr[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
   }
 }
 
@@ -263,8 +276,23 @@ __global__ __launch_bounds__(128) void length_regulate_kernel(const float* __res
                                                               const int32_t* __restrict__ mel_lens, const float* __restrict__ pos,
                                                               float* __restrict__ y, int L, int T, int H) {
   const int t = blockIdx.x, b = blockIdx.y;
-  const float4* pr = reinterpret_cast<const float4*>(pos + (long long)t * H);
   float4* yr = reinterpret_cast<float4*>(y + ((long long)b * T + t) * H);
+  if (!pos) {  // plain length regulator (frame-level pitch / energy follow before the decoder's positions, U/layers.py:241-257)
+    if (t >= mel_lens[b]) {
+      for (int i = threadIdx.x; i < H / 4; i += blockDim.x) yr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+    const int32_t* c = cum + b * L;
+    int lo = 0, hi = L - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (c[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    const float4* xr = reinterpret_cast<const float4*>(x + ((long long)b * L + lo) * H);
+    for (int i = threadIdx.x; i < H / 4; i += blockDim.x) yr[i] = xr[i];
+    return;
+  }
+  const float4* pr = reinterpret_cast<const float4*>(pos + (long long)t * H);
   if (t >= mel_lens[b]) {
     for (int i = threadIdx.x; i < H / 4; i += blockDim.x) yr[i] = pr[i];
     return;
@@ -278,6 +306,17 @@ __global__ __launch_bounds__(128) void length_regulate_kernel(const float* __res
   const float4* xr = reinterpret_cast<const float4*>(x + ((long long)b * L + lo) * H);
   for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
     const float4 a = xr[i], p = pr[i];
+    yr[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+
+// y[b, t, :] += pos[t, :] (the decoder's position add, when the length regulator could not carry it)
+__global__ __launch_bounds__(128) void add_positions_kernel(float* __restrict__ y, const float* __restrict__ pos, int T, int H) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  const float4* pr = reinterpret_cast<const float4*>(pos + (long long)t * H);
+  float4* yr = reinterpret_cast<float4*>(y + ((long long)b * T + t) * H);
+  for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
+    const float4 a = yr[i], p = pr[i];
     yr[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
   }
 }
@@ -720,25 +759,33 @@ const char* launch_duration(const float* log_d, float d_control, float* dur, int
 const char* launch_variance_embed(float* x, float* pitch_pred, const float* energy_pred, float p_control, float e_control,
                                   float f0_mean, float f0_std, const float* energy_bins, int n_bins, const float* pitch_emb,
                                   const float* energy_emb, int32_t* pitch_idx, int32_t* energy_idx, int B, int L, int H,
-                                  hipStream_t s, int pitch_mode, const float* pitch_bins) {
+                                  hipStream_t s, int pitch_mode, const float* pitch_bins, int feat) {
   if (!x || !pitch_pred || !energy_pred || !energy_bins || !pitch_emb || !energy_emb || !pitch_idx || !energy_idx)
     return "variance_embed: null pointer";
+  if (feat < 1 || feat > 3) return "variance_embed: bad feature mask";
   if (pitch_mode < 0 || pitch_mode > 2 || (pitch_mode == 2 && !pitch_bins)) return "variance_embed: bad pitch mode";
   if (n_bins != 256) return "variance_embed: the f0 coarse coding is defined for 256 bins (reference U/function.py:9)";
   // f0_mel_min / max: numpy float64 constants, used by torch as fp32 scalars (U/function.py:12-13,180)
   const double mel_min = 1127.0 * log(1.0 + 50.0 / 700.0), mel_max = 1127.0 * log(1.0 + 1100.0 / 700.0);
   hipLaunchKernelGGL(variance_embed_kernel, dim3(B * L), dim3(128), 0, s, x, pitch_pred, energy_pred, p_control, e_control,
                      f0_mean, f0_std, energy_bins, n_bins, pitch_emb, energy_emb, pitch_idx, energy_idx, H, (float)mel_min,
-                     (float)(mel_max - mel_min), pitch_mode, pitch_bins);
+                     (float)(mel_max - mel_min), pitch_mode, pitch_bins, feat);
   return CHECK_LAUNCH("variance_embed");
 }
 
 const char* launch_length_regulate(const float* x, const int32_t* cum, const int32_t* mel_lens, const float* pos, float* y,
                                    int B, int L, int T, int H, hipStream_t s) {
-  if (!x || !cum || !mel_lens || !pos || !y) return "length_regulate: null pointer";
+  if (!x || !cum || !mel_lens || !y) return "length_regulate: null pointer";   // pos == nullptr: no position add
   if (T <= 0 || H % 4) return "length_regulate: bad dims";
   hipLaunchKernelGGL(length_regulate_kernel, dim3(T, B), dim3(128), 0, s, x, cum, mel_lens, pos, y, L, T, H);
   return CHECK_LAUNCH("length_regulate");
+}
+
+const char* launch_add_positions(float* y, const float* pos, int B, int T, int H, hipStream_t s) {
+  if (!y || !pos) return "add_positions: null pointer";
+  if (T <= 0 || H % 4) return "add_positions: bad dims";
+  hipLaunchKernelGGL(add_positions_kernel, dim3(T, B), dim3(128), 0, s, y, pos, T, H);
+  return CHECK_LAUNCH("add_positions");
 }
 
 // S = (S + Sj) [/ div]: joins the stage sums of ResBlocks that ran side by side (engine.hip, small batches); the operations the

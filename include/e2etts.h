@@ -90,6 +90,10 @@ typedef struct e2etts_config {
   int32_t pitch_emb_rows; /* rows of pitch_embedding (U/layers.py:60-63: n_bins with use_uv, f0_bins without); 0 = n_bins */
   int32_t pred_pad_left;  /* variance_predictor.ffn_padding != "SAME" (U/layers.py:400-402,479-481): the three predictors' convolutions are padded
                              (k - 1, 0) -- causal -- instead of ((k - 1) / 2, (k - 1) / 2); 0 = SAME */
+  int32_t pitch_frame;    /* variance_embedding.pitch_feature == "frame_level" (U/layers.py:226-257): the pitch predictor and its embedding run on the */
+  int32_t energy_frame;   /* length regulator's output ([B, T] rows) instead of on the phonemes; likewise energy_feature.  0 = phoneme_level.  The
+                             frame-level feature's pitch_idx / pitch_pred / energy_idx / energy_pred then have T columns: e2etts_acoustic takes NULL
+                             for them and e2etts_fetch_tap / e2etts_fetch_tap_i32 hand them out afterwards (T is only known then) */
 } e2etts_config;
 
 /* Threading: every entry point takes the engine's internal mutex, so single calls are safe from any thread and distinct engines are
@@ -141,6 +145,9 @@ int e2etts_fetch_mel(e2etts_engine* engine, float* mel, float* mel_post);
 /* taps: "enc_out" [B, L, hidden], "dec_out" [B, T, hidden] (after e2etts_acoustic); "istft_spec_phase" [B, T * prod(voc_up_rate) + 1,
  * n_fft + 2] = exp / sin heads of the iSTFTNet generator (reference iSTFT.forward's return values), after a vocoder call. */
 int e2etts_fetch_tap(e2etts_engine* engine, const char* which, float* out, size_t n_floats);
+/* more taps of the last e2etts_acoustic, at the level the feature lives at (N = L for phoneme_level, T for frame_level):
+ * e2etts_fetch_tap: "pitch_pred" [B, N, 2] ([B, N] when pitch_no_uv), "energy_pred" [B, N]; e2etts_fetch_tap_i32: "pitch_idx", "energy_idx" [B, N]. */
+int e2etts_fetch_tap_i32(e2etts_engine* engine, const char* which, int32_t* out, size_t n_values);
 
 /* Replaces: HifiGan.forward (V/generator.py:37-53) on mel [B, n_mel, T] (the reference layout,
  * channels-first, as API/utils.py:144 passes it) or, when mel == NULL, on the resident mel_post of the

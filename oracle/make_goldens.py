@@ -115,6 +115,10 @@ def margins(out, energy_bins, stats, controls=(1.0, 1.0, 1.0), lens=None, ve=Non
     d = np.exp(out["log_d"].astype(np.float64)) - 1
     m_dur = np.abs((d - np.floor(d)) - 0.5)
     m_dur = np.where(valid, m_dur, 1.0)
+    # frame_level features (U/layers.py:249-257) have T columns; EVERY row counts there -- the embedding is added on padded rows too,
+    # and although the decoder masks those, the fixture stores their indices
+    valid_p = valid if out["pitch_pred"].shape[1] == L and not (ve is not None and ve["pitch_feature"] == "frame_level") else np.ones(out["pitch_pred"].shape[:2], bool)
+    valid_e = valid if out["energy_pred"].shape[1] == L and not (ve is not None and ve["energy_feature"] == "frame_level") else np.ones(out["energy_pred"].shape[:2], bool)
     p = out["pitch_pred"].astype(np.float64)  # already multiplied by p_control (U/layers.py:147)
     if ve is not None and not ve["use_uv"]:
         pb = np.asarray(pitch_bins, np.float64)
@@ -131,12 +135,12 @@ def margins(out, energy_bins, stats, controls=(1.0, 1.0, 1.0), lens=None, ve=Non
         # so the only boundaries are the half-integers of b and the uv threshold.
         fb = np.clip(b, 1, 255) + 0.5
         m_f0 = np.where(uv, 1.0, np.minimum(fb - np.floor(fb), np.ceil(fb) - fb))
-    m_f0 = np.where(valid, m_f0, 1.0)
-    m_uv = np.where(valid, m_uv, 1.0)
+    m_f0 = np.where(valid_p, m_f0, 1.0)
+    m_uv = np.where(valid_p, m_uv, 1.0)
     e = out["energy_pred"].astype(np.float64) * controls[2]
     m_en = np.abs(e[..., None] - energy_bins[None, None, :].astype(np.float64)).min(axis=-1)
     m_en = m_en / float(energy_bins[1] - energy_bins[0])  # in bucket units
-    m_en = np.where(valid, m_en, 1.0)
+    m_en = np.where(valid_e, m_en, 1.0)
     return dict(dur=float(m_dur.min()), uv=float(m_uv.min()), f0=float(m_f0.min()), energy=float(m_en.min()))
 
 
@@ -147,10 +151,22 @@ def oracle_margin(ac_oracle, ids, lens, speaker, stats, controls=(1.0, 1.0, 1.0)
     pad = orc.get_mask_from_lengths(lens, ids.shape[1])
     x = ac_oracle.encoder(ids, pad) + ac_oracle.sd["speaker_emb.weight"][[speaker]][:, None, :]
     ve = ac_oracle.fs["variance"]["variance_embedding"]
-    pp = ac_oracle.variance_predictor("pitch", x)
-    out = dict(log_d=ac_oracle.duration_predictor(x, pad),
+    log_d = ac_oracle.duration_predictor(x, pad)
+    xp = xe = x
+    if ve["pitch_feature"] == "frame_level" or ve["energy_feature"] == "frame_level":   # those predictors read the regulator's output
+        dur = np.maximum(np.round(np.exp(log_d) - np.float32(1)) * np.float32(controls[0]), np.float32(0))
+        x_tmp = x
+        if ve["pitch_feature"] != "frame_level":
+            x_tmp = x_tmp + ac_oracle.pitch_embedding(x, controls[1])[2]
+        if ve["energy_feature"] != "frame_level":
+            x_tmp = x_tmp + ac_oracle.energy_embedding(x, controls[2])[2]
+        xf, _ = ac_oracle.length_regulator(x_tmp, dur)
+        xp = xf if ve["pitch_feature"] == "frame_level" else x
+        xe = xf if ve["energy_feature"] == "frame_level" else x
+    pp = ac_oracle.variance_predictor("pitch", xp)
+    out = dict(log_d=log_d,
                pitch_pred=pp * np.float32(controls[1]) if ve["use_uv"] else pp[..., 0],
-               energy_pred=ac_oracle.variance_predictor("energy", x)[..., 0])
+               energy_pred=ac_oracle.variance_predictor("energy", xe)[..., 0])
     return margins(out, ac_oracle.sd["variance_adaptor.energy_bins"], stats, controls, lens, ve, ac_oracle.sd["variance_adaptor.pitch_bins"])
 
 
@@ -569,6 +585,8 @@ def main():
         "tiny_nouv_b3": lambda: case_model(models, "tiny_nouv_b3", pv_variant(cfgmod.tiny_config(), "nouv"), "varied", [19, 26, 8], 1, (1.0, 1.1, 0.9), 1300, 2e-3, "full"),
         "tiny_plog_b3": lambda: case_model(models, "tiny_plog_b3", pv_variant(cfgmod.tiny_config(), "plog"), "varied", [19, 26, 8], 3, (1.0, 1.0, 1.0), 1400, 2e-3, "full"),
         "tiny_lpad_b3": lambda: case_model(models, "tiny_lpad_b3", pv_variant(cfgmod.tiny_config(), "lpad"), "varied", [17, 28, 5], 2, (1.0, 1.0, 1.0), 1500, 2e-3, "full"),
+        "tiny_frame_b3": lambda: case_model(models, "tiny_frame_b3", pv_variant(cfgmod.tiny_config(), "frame"), "varied", [14, 22, 6], 1, (1.0, 1.0, 1.0), 1600, 1e-3, "full", max_tries=80),
+        "tiny_pframe_b3": lambda: case_model(models, "tiny_pframe_b3", pv_variant(cfgmod.tiny_config(), "pframe"), "varied", [14, 22, 6], 0, (1.0, 1.05, 0.95), 1700, 1e-3, "full", max_tries=80),
         "c1_plumbing": lambda: case_model(models, "c1_plumbing", full, "varied", [40], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
         "full_b3": lambda: case_model(models, "full_b3", full, "varied", [48, 31, 20], 1, (1.0, 1.0, 1.0), 500, 1e-3, "medium"),
     }
@@ -607,8 +625,12 @@ def pv_variant(cfg, which):
         ve["use_uv"] = False
     elif which == "plog":
         ve["pitch_quantization"] = "log"
-    else:   # "lpad": variance_predictor.ffn_padding "LEFT" -- causal predictor convolutions (U/layers.py:400-402,479-481)
+    elif which == "lpad":   # variance_predictor.ffn_padding "LEFT" -- causal predictor convolutions (U/layers.py:400-402,479-481)
         cfg["models"]["fastspeech2"]["variance"]["variance_predictor"]["ffn_padding"] = "LEFT"
+    elif which == "frame":  # both features at the frame level (U/layers.py:249-257)
+        ve["pitch_feature"] = ve["energy_feature"] = "frame_level"
+    else:                   # "pframe": pitch at the frame level, energy on the phonemes
+        ve["pitch_feature"] = "frame_level"
     return cfg
 
 

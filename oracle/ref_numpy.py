@@ -474,10 +474,24 @@ class AcousticOracle:
         log_d = self.duration_predictor(x, pad)
         # U/layers.py:218-221: round half-to-even, control applied after rounding, clamp >= 0
         dur = np.maximum(np.round(np.exp(log_d) - dt(1)) * dt(d_control), dt(0))
-        p_pred, p_idx, p_emb = self.pitch_embedding(x, p_control)
-        e_pred, e_idx, e_emb = self.energy_embedding(x, e_control)
-        x = x + p_emb + e_emb
-        x, mel_lens = self.length_regulator(x, dur)
+        ve = self.fs["variance"]["variance_embedding"]
+        p_frame, e_frame = ve["pitch_feature"] == "frame_level", ve["energy_feature"] == "frame_level"
+        x_tmp = x                                                                         # U/layers.py:225-239: phoneme_level features
+        if not p_frame:
+            p_pred, p_idx, p_emb = self.pitch_embedding(x, p_control)
+            x_tmp = x_tmp + p_emb
+        if not e_frame:
+            e_pred, e_idx, e_emb = self.energy_embedding(x, e_control)
+            x_tmp = x_tmp + e_emb
+        x, mel_lens = self.length_regulator(x_tmp, dur)
+        x_tmp = x                                                                         # :248-257: frame_level features, both predicted from
+        if p_frame:                                                                       # the regulator's output, padded rows included
+            p_pred, p_idx, p_emb = self.pitch_embedding(x, p_control)
+            x_tmp = x_tmp + p_emb
+        if e_frame:
+            e_pred, e_idx, e_emb = self.energy_embedding(x, e_control)
+            x_tmp = x_tmp + e_emb
+        x = x_tmp
         self.trace.update(log_d=log_d, pitch_pred=p_pred, pitch_idx=p_idx, energy_pred=e_pred, energy_idx=e_idx, lr_out=x)
         mel_pad = get_mask_from_lengths(mel_lens)
         x = self.decoder(x, mel_pad)

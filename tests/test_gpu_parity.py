@@ -22,7 +22,7 @@ _ENGINES = {}
 def engine_for(g, name):
     from e2e_tts_amd.runtime import engine_from_states
     cfg, ac, voc = states_for(g, name)
-    key = (name.startswith("tiny"), "_cf_" in name, "_hv_" in name, "_nouv_" in name, "_plog_" in name, "_lpad_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
+    key = (name.startswith("tiny"), "_cf_" in name, "_hv_" in name, "_nouv_" in name, "_plog_" in name, "_lpad_" in name, "_frame_" in name, "_pframe_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
     if key not in _ENGINES:
         _ENGINES[key] = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)
     return cfg, _ENGINES[key]
@@ -52,7 +52,7 @@ def check_discrete(r, g):
 # *_cf_*: the same model with Conformer blocks (building_block.block_type = "conformer", reference U/blocks/conformer.py);
 # tiny_cf_long runs past max_seq_len in the encoder and the decoder (regenerated position tables in every attention module)
 @pytest.mark.parametrize("name", ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1", "tiny_cf_b3", "tiny_cf_long", "tiny_hv_b3", "tiny_cf_hv_b3",
-                                  "tiny_nouv_b3", "tiny_plog_b3", "tiny_lpad_b3"])
+                                  "tiny_nouv_b3", "tiny_plog_b3", "tiny_lpad_b3", "tiny_frame_b3", "tiny_pframe_b3"])
 def test_tiny_model_full_trace(name):
     g = load_golden(name)
     cfg, eng = engine_for(g, name)
@@ -558,7 +558,7 @@ def test_conformer_rejects_sequences_beyond_the_position_table():
         eng.acoustic(rng.integers(4, 131, size=(1, 100)).astype(np.int64), np.array([100], np.int64), np.array([0], np.int64))
 
 
-@pytest.mark.parametrize("name", ["tiny_b3", "tiny_ctl", "full_b3", "c3_mixed", "full_long", "tiny_cf_b3", "tiny_hv_b3", "tiny_cf_hv_b3"])
+@pytest.mark.parametrize("name", ["tiny_b3", "tiny_ctl", "full_b3", "c3_mixed", "full_long", "tiny_cf_b3", "tiny_hv_b3", "tiny_cf_hv_b3", "tiny_frame_b3", "tiny_pframe_b3"])
 def test_ragged_synthesize_is_bit_identical_on_valid_samples(name):
     """synthesize() with ragged compute (skip what no valid sample depends on) vs the full padded batch: same PCM on every
     valid sample, and within 1 LSB of the reference's waveform there."""
@@ -1067,3 +1067,27 @@ def test_random_model_geometries_match_the_oracle(seed):
                 np.testing.assert_array_equal(rag[b, :n], full[b, :n])
     finally:
         eng.close()
+
+
+def test_frame_level_outputs_are_taps_not_acoustic_outputs():
+    """variance_embedding.*_feature "frame_level" (reference U/layers.py:249-257): the feature's index / prediction arrays have T columns, which
+    the caller cannot size before the call -- e2etts_acoustic refuses a buffer for them and the taps hand them out afterwards."""
+    import ctypes as C
+    g = load_golden("tiny_pframe_b3")
+    cfg, eng = engine_for(g, "tiny_pframe_b3")
+    spk = np.array([int(g["speaker"])], np.int64)
+    d, p, e = (float(x) for x in g["controls"])
+    r = eng.acoustic(g["ids"], g["lens"], spk, d, p, e, want=("pitch_idx", "energy_idx", "pitch_pred", "energy_pred", "mel_lens"))
+    B, L, T = g["ids"].shape[0], g["ids"].shape[1], r["T"]
+    assert r["pitch_idx"].shape == (B, T) and r["pitch_pred"].shape == (B, T, 2)      # frame level
+    assert r["energy_idx"].shape == (B, L) and r["energy_pred"].shape == (B, L)       # phoneme level
+    np.testing.assert_array_equal(r["pitch_idx"], g["pitch_idx"])
+    np.testing.assert_array_equal(r["energy_idx"], g["energy_idx"])
+    ids, lens = np.ascontiguousarray(g["ids"]), np.ascontiguousarray(g["lens"])
+    buf = np.zeros((B, L), np.int32)
+    Tc = C.c_int(0)
+    rc = eng.lib.e2etts_acoustic(eng._h, ids.ctypes.data, lens.ctypes.data, B, L, spk.ctypes.data, 1, d, p, e,
+                                 None, None, C.byref(Tc), buf.ctypes.data, None, None, None, None)
+    assert rc != 0 and b"frame_level" in eng.lib.e2etts_last_error(eng._h)
+    wrong = np.zeros(5, np.int32)
+    assert eng.lib.e2etts_fetch_tap_i32(eng._h, b"pitch_idx", wrong.ctypes.data, wrong.size) != 0

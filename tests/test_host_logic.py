@@ -144,12 +144,12 @@ def test_c_abi_library_exports_every_declared_symbol():
         import __graft_entry__ as g
         g.build()
     header = open(os.path.join(ROOT, "include", "e2etts.h")).read()
-    declared = sorted(set(re.findall(r"\b(e2etts_[a-z_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(e2etts_[a-z0-9_]+)\s*\(", header)))
     assert declared == sorted(_lib.EXPORTED_SYMBOLS)
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert ctypes.sizeof(cfgmod.CEngineConfig) == 4 * (23 + 8 + 8 + 1 + 4 + 1 + 16 + 3) + 8 + 4 * 11  # + voc_resblock, voc_istft_nfft, voc_istft_hop, block_type, energy_layers, energy_kernel, dec_n_head, pitch_no_uv, pitch_log2, pitch_emb_rows, pred_pad_left
+    assert ctypes.sizeof(cfgmod.CEngineConfig) == 4 * (23 + 8 + 8 + 1 + 4 + 1 + 16 + 3) + 8 + 4 * 13  # + voc_resblock, voc_istft_nfft, voc_istft_hop, block_type, energy_layers, energy_kernel, dec_n_head, pitch_no_uv, pitch_log2, pitch_emb_rows, pred_pad_left, pitch_frame, energy_frame
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -1010,6 +1010,18 @@ def _random_geometry(seed):
               resblock_kernel_sizes=[pick([3, 5, 7, 11]) for _ in range(nk)],
               resblock_dilation_sizes=[[pick([1, 2, 3, 5]) for _ in range(nd)] for _ in range(nk)])
     cfg["audio"]["stft"]["hop_length"] = int(np.prod(rates))
+    # the variance adaptor's configuration knobs (U/layers.py:48-104,136-160,226-257,400-402), one per seed
+    ve = fs["variance"]["variance_embedding"]
+    if seed == 2:
+        ve["use_uv"] = False
+    if seed == 4:
+        vp["ffn_padding"] = "LEFT"
+    if seed == 5:
+        ve["pitch_feature"] = ve["energy_feature"] = "frame_level"
+    if seed == 6:
+        ve["pitch_quantization"] = "log"
+    if seed == 103:
+        ve["energy_feature"] = "frame_level"
     if seed >= 100:   # Conformer blocks (U/blocks/conformer.py:31-36): head dims 8 .. 96, depthwise kernels with and without a fused instantiation
         hidden, heads = pick([(64, 8), (64, 4), (96, 2), (128, 4), (96, 1), (192, 4)])
         fs["encoder_hidden"] = fs["decoder_hidden"] = hidden

@@ -257,7 +257,10 @@ def _pack_acoustic(dims: EngineDims, A, out) -> None:
         out[f"{short}.lin.b"] = need(A, f"{va}.{name}.linear.bias", (odim,))
         if short != "dur":
             out[f"{short}.alpha"] = need(A, f"{va}.{name}.pos_embed_alpha", (1,))
-    out["var.pos"] = variance_position_table(VAR_POS_INIT_ROWS, H)
+    # (frame_level features index it by frame: rows for every T the decoder's own table allows -- the reference grows its table on demand,
+    # U/sublayers.py:56-60, with the same function, so the rows below 4096 are the same)
+    var_rows = max(VAR_POS_INIT_ROWS, dims.pos_table_rows + 2) if (dims.pitch_frame or dims.energy_frame) else VAR_POS_INIT_ROWS
+    out["var.pos"] = variance_position_table(var_rows, H)
     out["pitch.emb"] = need(A, f"{va}.pitch_embedding.weight", (dims.pitch_emb_rows or dims.n_bins, H))
     if dims.pitch_no_uv:
         out["pitch.bins"] = need(A, f"{va}.pitch_bins", (dims.n_bins - 1,))

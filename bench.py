@@ -76,24 +76,54 @@ def self_launch(n: int, argv) -> int:
     base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL across processes needs it)
     base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
-    procs = []
+    import threading
+    procs, errs, tails = [], [], []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # every rank's stderr goes through this parent: relayed live, and its last lines kept so that a failure can be named
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()       # rank 0 prints the one JSON line; everything else it writes goes to stderr already
-    rc = procs[0].returncode
-    deadline = time.time() + (30 if rc else 600)
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()                       # exactly the child this parent started
-            p.wait()
-        rc = rc or p.returncode
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+        tails.append([])
+
+        def relay(p=procs[-1], tail=tails[-1]):
+            for line in p.stderr:
+                sys.stderr.write(line)
+                sys.stderr.flush()
+                if line.strip():
+                    tail.append(line.rstrip())
+                    del tail[:-5]
+        errs.append(threading.Thread(target=relay, daemon=True))
+        errs[-1].start()
+    out0 = procs[0].stdout.read()          # rank 0 prints the one JSON line; everything else the ranks write goes to stderr
+    first_fail = None                      # (rank, exit code) of the rank that failed FIRST: the others usually die of its absence
+    deadline = None
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc_r = procs[r].poll()
+            if rc_r is None:
+                continue
+            alive.discard(r)
+            if rc_r != 0 and first_fail is None:
+                first_fail = (r, rc_r)
+                deadline = time.time() + 30   # the others get half a minute to notice, then are killed by their exact PIDs
+        if alive and deadline is not None and time.time() > deadline:
+            for r in sorted(alive):
+                procs[r].kill()            # exactly the children this parent started
+                procs[r].wait()
+            alive.clear()
+        if alive:
+            time.sleep(0.05)
+    for t in errs:
+        t.join(timeout=5)
     for line in (out0 or "").splitlines():
-        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
-    return rc if rc is not None else 1
+        print(line, file=sys.stdout if line.startswith("{") and first_fail is None else sys.stderr, flush=True)
+    if first_fail is not None:
+        r, rc_r = first_fail
+        last = tails[r][-1] if tails[r] else "(no output on stderr)"
+        log(f"[bench] launcher: rank {r} failed first (exit code {rc_r}); its last stderr line: {last}")
+        return rc_r if rc_r > 0 else 1
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -397,6 +427,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or call bench.py plainly and let it start them)")
     if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if not stub and os.environ.get("E2ETTS_BENCH_REHEARSAL") != "1" and torch.cuda.device_count() < world:
+        # before init_process_group: otherwise the ranks beyond the last GPU die inside torch with "invalid device ordinal"
+        raise SystemExit(f"bench.py --gpus {world}: WORLD_SIZE={world} ranks but only {torch.cuda.device_count()} GPU(s) visible to rank {rank} "
+                         f"(one rank per GPU; E2ETTS_BENCH_REHEARSAL=1 rehearses the N > 1 path on one GPU under gloo)")
     # Rehearsal of the N > 1 path on a one-GPU box (E2ETTS_BENCH_REHEARSAL=1): every rank uses GPU 0 and the collectives go
     # through gloo, since RCCL refuses two ranks on one device.  Never used for a reported number.
     rehearsal = os.environ.get("E2ETTS_BENCH_REHEARSAL") == "1"

@@ -14,6 +14,10 @@ from .config import CEngineConfig, EngineDims
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libe2etts_hip.so")
+# The TEST build of the same sources (-DE2ETTS_TEST_HOOKS: one more export, e2etts_debug_poison_workspace).  Loaded instead of the product
+# library only when E2ETTS_TEST_HOOKS=1 is in the environment (tests/conftest.py sets it); nothing in the product path asks for it.
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "libe2etts_hip_test.so")
+ABI_VERSION = 4   # E2ETTS_ABI_VERSION of the include/e2etts.h this binding mirrors
 
 E_OK, E_INVAL, E_HIP, E_STATE, E_NOMEM, E_KEY = 0, -1, -2, -3, -4, -5
 
@@ -31,18 +35,32 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    hooks = os.environ.get("E2ETTS_TEST_HOOKS", "") not in ("", "0")
+    path = TEST_LIB_PATH if hooks else LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  e2e_tts_amd has no CPU fallback.")
     # ONE HIP runtime per process: torch ships its own libamdhip64.so (soname libamdhip64.so.7) and resolves it by file name, so if this
     # library -- which needs "libamdhip64.so.7" -- were loaded first it would pull in /opt/rocm's copy and a later `import torch` would
     # bring a second runtime that finds no GPU ("No HIP GPUs are available").  With torch loaded first the soname matches its copy.
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     P, I, F, SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     lib.e2etts_version.restype = C.c_char_p
     lib.e2etts_version.argtypes = []
+    # ABI guard before anything else is bound: the library's header revision and its sizeof(e2etts_config) must be the ones this
+    # binding's hand-written mirror (config.CEngineConfig) was written for -- a stale .so or a drifted mirror fails here, loudly
+    try:
+        lib.e2etts_abi_version.restype = I
+        lib.e2etts_abi_version.argtypes = []
+        lib.e2etts_config_size.restype = SZ
+        lib.e2etts_config_size.argtypes = []
+    except AttributeError as ex:
+        raise ImportError(f"{path} predates the ABI guard (no e2etts_abi_version / e2etts_config_size): rebuild it") from ex
+    if lib.e2etts_abi_version() != ABI_VERSION or lib.e2etts_config_size() != C.sizeof(CEngineConfig):
+        raise ImportError(f"{path}: ABI version {lib.e2etts_abi_version()} / sizeof(e2etts_config) {lib.e2etts_config_size()}, this binding "
+                          f"mirrors version {ABI_VERSION} / {C.sizeof(CEngineConfig)} bytes: rebuild the library or update config.CEngineConfig")
     lib.e2etts_last_error.restype = C.c_char_p
     lib.e2etts_last_error.argtypes = [P]
     lib.e2etts_create.restype = I
@@ -85,8 +103,9 @@ def load_library() -> C.CDLL:
     lib.e2etts_set_precision.argtypes = [P, I, I]
     lib.e2etts_set_ragged.restype = I
     lib.e2etts_set_ragged.argtypes = [P, I]
-    lib.e2etts_debug_poison_workspace.restype = I
-    lib.e2etts_debug_poison_workspace.argtypes = [P]
+    if hooks:
+        lib.e2etts_debug_poison_workspace.restype = I
+        lib.e2etts_debug_poison_workspace.argtypes = [P]
     lib.e2etts_set_fused_resblocks.restype = I
     lib.e2etts_set_fused_resblocks.argtypes = [P, I]
     lib.e2etts_profile_enable.restype = I
@@ -105,11 +124,14 @@ def load_library() -> C.CDLL:
     return lib
 
 
+# every entry point include/e2etts.h declares for the product library -- and, with -fvisibility=hidden, ALL it exports
+# (tests/test_host_logic.py compares this list with the header and with `nm -D`); the test build adds TEST_HOOK_SYMBOLS
+TEST_HOOK_SYMBOLS = ["e2etts_debug_poison_workspace"]
 EXPORTED_SYMBOLS = [
-    "e2etts_version", "e2etts_last_error", "e2etts_create", "e2etts_destroy", "e2etts_load_weights", "e2etts_acoustic",
+    "e2etts_version", "e2etts_abi_version", "e2etts_config_size", "e2etts_last_error", "e2etts_create", "e2etts_destroy", "e2etts_load_weights", "e2etts_acoustic",
     "e2etts_fetch_mel", "e2etts_fetch_tap", "e2etts_fetch_tap_i32", "e2etts_vocoder", "e2etts_vocoder_btc", "e2etts_synthesize", "e2etts_fetch_pcm",
     "e2etts_fetch_wav", "e2etts_vocoder_stream_begin", "e2etts_vocoder_stream_push", "e2etts_vocoder_stream_fetch",
-    "e2etts_set_precision", "e2etts_set_ragged", "e2etts_debug_poison_workspace", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_filter", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
+    "e2etts_set_precision", "e2etts_set_ragged", "e2etts_set_fused_resblocks", "e2etts_profile_enable", "e2etts_profile_filter", "e2etts_profile_read", "e2etts_device_bytes", "e2etts_stream", "e2etts_sync",
     "e2etts_load_weights_bcast", "e2etts_order_after", "e2etts_tempo",
 ]
 
@@ -385,7 +407,11 @@ class Engine:
 
     @_locked
     def poison_workspace(self):
-        """Test hook: fill the activation workspaces with a large finite pattern (ragged-mode tests: nothing valid may depend on stale rows)."""
+        """Test hook (test build of the library only, E2ETTS_TEST_HOOKS=1): fill the activation workspaces with a large finite pattern
+        (ragged-mode tests: nothing valid may depend on stale rows)."""
+        if not hasattr(self.lib, "e2etts_debug_poison_workspace"):
+            raise RuntimeError("e2etts_debug_poison_workspace is a test hook: set E2ETTS_TEST_HOOKS=1 before the library is loaded "
+                               "(libe2etts_hip_test.so); the product library does not export it")
         self._check(self.lib.e2etts_debug_poison_workspace(self._h), "e2etts_debug_poison_workspace")
 
     @_locked

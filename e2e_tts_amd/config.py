@@ -153,9 +153,12 @@ MAX_DILATIONS = 4
 
 
 class CEngineConfig(ctypes.Structure):
-    """Mirror of ``e2etts_config`` in include/e2etts.h (keep in sync)."""
+    """Mirror of ``e2etts_config`` in include/e2etts.h.  Kept in sync by two checks, not by hand alone: ``_lib.load_library`` refuses a
+    library whose ``e2etts_config_size()`` differs from ``ctypes.sizeof`` of this class, and tests/test_host_logic.py compares the field
+    names and order with the header's text."""
 
     _fields_ = [
+        ("struct_size", ctypes.c_uint32),
         ("n_symbols", ctypes.c_int32),
         ("n_speakers", ctypes.c_int32),
         ("n_mel", ctypes.c_int32),
@@ -269,6 +272,7 @@ class EngineDims:
 
     def to_c(self) -> CEngineConfig:
         c = CEngineConfig()
+        c.struct_size = ctypes.sizeof(CEngineConfig)
         for name in (
             "n_symbols n_speakers n_mel hidden enc_layers dec_layers n_head ffn_dim ffn_k1 ffn_k2 "
             "max_seq_len dur_layers dur_kernel dur_chans var_layers var_kernel var_chans n_bins "

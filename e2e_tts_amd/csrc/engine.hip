@@ -1345,13 +1345,29 @@ extern "C" {
 #ifndef E2ETTS_SRC_HASH
 #define E2ETTS_SRC_HASH "unknown"
 #endif
-const char* e2etts_version(void) { return "e2etts-hip 0.3 (gfx950; fp32 MFMA + bf16x3 split-precision MFMA) E2ETTS_SRC_HASH=" E2ETTS_SRC_HASH; }
+const char* e2etts_version(void) { return "e2etts-hip 0.4 (gfx950; fp32 MFMA + bf16x3 split-precision MFMA) E2ETTS_SRC_HASH=" E2ETTS_SRC_HASH; }
+
+// The struct layout is part of the ABI: a change of its size must come with a new E2ETTS_ABI_VERSION (and a new row in the sizes
+// e2etts_create accepts), never silently.
+static_assert(sizeof(e2etts_config) == 320, "e2etts_config changed size: bump E2ETTS_ABI_VERSION and review e2etts_create's size check");
+static_assert(offsetof(e2etts_config, struct_size) == 0, "struct_size must stay the first field");
+int e2etts_abi_version(void) { return E2ETTS_ABI_VERSION; }
+size_t e2etts_config_size(void) { return sizeof(e2etts_config); }
 
 const char* e2etts_last_error(const e2etts_engine* engine) { return engine ? engine->err.c_str() : g_create_error.c_str(); }
 
 int e2etts_create(int device_id, const e2etts_config* cfg, e2etts_engine** out) {
   if (!cfg || !out) { g_create_error = "cfg / out must not be NULL"; return E2ETTS_EINVAL; }
   *out = nullptr;
+  // Nothing of *cfg is read before its size is known to be this header's: a host compiled against another revision of the struct
+  // would otherwise be read out of bounds (or have its fields mistaken for others).
+  if (cfg->struct_size != (uint32_t)sizeof(e2etts_config)) {
+    char m[192];
+    snprintf(m, sizeof m, "e2etts_config.struct_size = %u is not a size this library knows (sizeof(e2etts_config) = %zu, ABI version %d): "
+             "the caller was built against another revision of e2etts.h", (unsigned)cfg->struct_size, sizeof(e2etts_config), E2ETTS_ABI_VERSION);
+    g_create_error = m;
+    return E2ETTS_EINVAL;
+  }
   const e2etts_config& c = *cfg;
   auto bad = [&](const char* m) { g_create_error = m; return E2ETTS_EINVAL; };
   if (const char* m = config_check(c)) return bad(m);
@@ -1799,9 +1815,13 @@ int e2etts_set_ragged(e2etts_engine* e, int enable) {
   return E2ETTS_OK;
 }
 
+#ifdef E2ETTS_TEST_HOOKS
 int e2etts_debug_poison_workspace(e2etts_engine* e) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
+  // what the workspaces held is gone: taps, fetches and vocoder(NULL) must say so instead of handing out the pattern
+  e->have_acoustic = false;
+  e->have_wav = false;
   DevBuf* bufs[] = {&e->xa, &e->xb, &e->xs, &e->xp, &e->tmp, &e->qkv, &e->att, &e->hid, &e->p1, &e->p2, &e->attws, &e->dx, &e->dxb, &e->mel,
                     &e->melpost, &e->pn1, &e->pn2, &e->melin, &e->v0, &e->v1, &e->v2, &e->v3, &e->wav, &e->pcm, &e->istft_q, &e->istft_ri, &e->istft_sp};
   for (DevBuf* b : bufs)
@@ -1812,6 +1832,7 @@ int e2etts_debug_poison_workspace(e2etts_engine* e) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return E2ETTS_OK;
 }
+#endif  // E2ETTS_TEST_HOOKS
 
 int e2etts_set_fused_resblocks(e2etts_engine* e, int level) {
   if (!e) return E2ETTS_EINVAL;

@@ -32,13 +32,26 @@ def _world_rank() -> Tuple[int, int]:
     return 1, 0
 
 
+def _collective_device(device=None):
+    """Where the collectives' tensors live.  An explicit `device` wins; otherwise the process group decides: backend "nccl" (RCCL) moves
+    device memory only -- a CPU tensor there raises 'No backend type associated with device type cpu' on every rank -- so the default is
+    this process's current cuda device; gloo (CPU tests) and no group at all default to the host."""
+    import torch
+    import torch.distributed as dist
+    if device is not None:
+        return torch.device(device)
+    if dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend()).lower():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def broadcast_blob(blob: Optional[np.ndarray], src: int = 0, device=None):
     """Broadcast the packed weight image from rank `src`; returns a uint8 torch tensor on `device`
-    (HBM when device is a cuda device: e2etts_load_weights then copies device-to-device)."""
+    (HBM when device is a cuda device: e2etts_load_weights then copies device-to-device; default: `_collective_device`)."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank()
-    dev = torch.device(device) if device is not None else torch.device("cpu")
+    dev = _collective_device(device)
     n = torch.tensor([blob.size if rank == src else 0], dtype=torch.int64, device=dev)
     dist.broadcast(n, src=src)
     if rank == src:
@@ -55,17 +68,22 @@ def gather_pcm(local: List[Tuple[int, np.ndarray]], dst: int = 0, device=None, s
     Tensor collectives only (no pickling of the payload): every rank sends ONE flat int16 tensor -- its PCM back to back, padded to the
     longest rank's total -- plus a small (index, sample count) table, and `dst` slices views out of what it received.  `device`: where
     the collectives run -- a cuda device under backend "nccl" (RCCL moves device memory: the PCM takes one H2D copy here, rides xGMI,
-    and `dst` brings all of it back with ONE D2H copy into page-locked memory), None / "cpu" under gloo.
-    `stats` (optional dict) receives `samples_per_rank` on `dst`."""
+    and `dst` brings all of it back with ONE D2H copy into page-locked memory), the host under gloo; None picks by backend
+    (`_collective_device`).  `stats` (optional dict) receives `samples_per_rank` on `dst`.
+    Every (index, PCM) pair is validated BEFORE the first collective: a rank with a bad entry must not raise alone between two
+    collectives and leave the others waiting in the next one."""
     import torch
     import torch.distributed as dist
     world, rank = _world_rank()
+    for idx, pcm in local:
+        if not isinstance(pcm, np.ndarray) or pcm.dtype != np.int16 or pcm.ndim != 1:
+            raise TypeError(f"gather_pcm: PCM of utterance {idx} must be a 1-D int16 array")
     if world == 1 and not (_force_collectives and dist.is_initialized()):   # (_force_collectives: tests run the tensor path on a one-rank group)
         merged = sorted(local, key=lambda kv: kv[0])
         if stats is not None:
             stats["samples_per_rank"] = [int(sum(p.size for _, p in local))]
         return merged
-    dev = torch.device(device) if device is not None else torch.device("cpu")
+    dev = _collective_device(device)
     n_local = len(local)
     total = int(sum(p.size for _, p in local))
     head = torch.tensor([n_local, total], dtype=torch.int64, device=dev)
@@ -73,8 +91,6 @@ def gather_pcm(local: List[Tuple[int, np.ndarray]], dst: int = 0, device=None, s
     max_n, max_total = int(head[0].item()), int(head[1].item())
     table = torch.full((max(max_n, 1), 2), -1, dtype=torch.int64)
     for k, (idx, pcm) in enumerate(local):
-        if pcm.dtype != np.int16 or pcm.ndim != 1:
-            raise TypeError("gather_pcm: PCM must be 1-D int16")
         table[k, 0], table[k, 1] = int(idx), int(pcm.size)
     tables = [torch.empty_like(table, device=dev) for _ in range(world)]
     dist.all_gather(tables, table.to(dev))
@@ -119,7 +135,7 @@ def _agree_or_raise(failure: Optional[BaseException], device=None) -> None:
         if failure is not None:
             raise failure
         return
-    dev = torch.device(device) if device is not None else torch.device("cpu")
+    dev = _collective_device(device)
     ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if failure is not None:

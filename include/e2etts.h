@@ -35,6 +35,17 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#define E2ETTS_API __attribute__((visibility("default")))
+#else
+#define E2ETTS_API
+#endif
+
+/* ABI revision of this header: bumped whenever a struct layout or a signature changes.  A host checks e2etts_abi_version() ==
+ * E2ETTS_ABI_VERSION (the Python binding does at load) and fills e2etts_config.struct_size, which e2etts_create checks. */
+#define E2ETTS_ABI_VERSION 4
+
 #define E2ETTS_MAX_STAGES 8
 #define E2ETTS_MAX_RB_KERNELS 4
 #define E2ETTS_MAX_DILATIONS 4
@@ -48,6 +59,9 @@ extern "C" {
 
 /* Dimensions parsed from the reference's config.yaml (API/utils.py:34; e2e_tts/config/model_config.yaml). */
 typedef struct e2etts_config {
+  uint32_t struct_size;   /* = sizeof(e2etts_config) of the header the CALLER was compiled against.  e2etts_create reads nothing beyond
+                             it and refuses (E2ETTS_EINVAL) a size it does not know: a host built against an older or newer header gets an
+                             error instead of garbage fields.  This revision knows exactly one size, e2etts_config_size(). */
   int32_t n_symbols;      /* len(symbols) = 131; the embedding has n_symbols + 1 rows (U/blocks/transformer.py:25) */
   int32_t n_speakers;
   int32_t n_mel;          /* audio.mel.channels */
@@ -103,19 +117,23 @@ typedef struct e2etts_config {
 typedef struct e2etts_engine e2etts_engine;
 
 /* Library / build identification. */
-const char* e2etts_version(void);
+E2ETTS_API const char* e2etts_version(void);
+/* E2ETTS_ABI_VERSION of the header the library was built from, and its sizeof(e2etts_config): what a binding compares its own mirror
+ * of the struct with before it calls e2etts_create (e2e_tts_amd/_lib.py: load_library). */
+E2ETTS_API int e2etts_abi_version(void);
+E2ETTS_API size_t e2etts_config_size(void);
 
 /* Last error message of this engine (or of a failed e2etts_create when engine == NULL). */
-const char* e2etts_last_error(const e2etts_engine* engine);
+E2ETTS_API const char* e2etts_last_error(const e2etts_engine* engine);
 
 /* Replaces: TTS.__init__ model construction + .to(device) (API/utils.py:41-56). */
-int e2etts_create(int device_id, const e2etts_config* cfg, e2etts_engine** out);
-void e2etts_destroy(e2etts_engine* engine);
+E2ETTS_API int e2etts_create(int device_id, const e2etts_config* cfg, e2etts_engine** out);
+E2ETTS_API void e2etts_destroy(e2etts_engine* engine);
 
 /* Replaces: load_state_dict for both models (API/utils.py:48-49,54-55).  `blob` is the packed weight
  * image (host or device memory; a device image is what a RCCL broadcast from rank 0 leaves behind --
  * SURVEY.md 8(e)); it is copied into engine-owned HBM. */
-int e2etts_load_weights(e2etts_engine* engine, const void* blob, size_t nbytes);
+E2ETTS_API int e2etts_load_weights(e2etts_engine* engine, const void* blob, size_t nbytes);
 
 /* Multi-GPU start-up (no reference line: the reference is single-device): ONE RCCL broadcast of the packed
  * image from rank `root` of `rccl_comm` (an ncclComm_t of the RCCL copy the host process links or has loaded; every rank's
@@ -124,7 +142,7 @@ int e2etts_load_weights(e2etts_engine* engine, const void* blob, size_t nbytes);
  * (host or device memory) is read on the root only.  RCCL is resolved at the first call (process image, else librccl.so.1 or
  * $E2ETTS_RCCL_LIB); E2ETTS_ESTATE if it cannot be.  Hosts that drive RCCL through torch.distributed broadcast a tensor and
  * call e2etts_load_weights on it instead (e2e_tts_amd/dist.py) -- torch does not expose its ncclComm_t. */
-int e2etts_load_weights_bcast(e2etts_engine* engine, const void* blob_or_null, size_t nbytes, void* rccl_comm, int root);
+E2ETTS_API int e2etts_load_weights_bcast(e2etts_engine* engine, const void* blob_or_null, size_t nbytes, void* rccl_comm, int root);
 
 /* Replaces: UnsupervisedFastSpeech2.inference (U/model.py:155-194).
  *   ids  [B, L] int64, lens [B] int64 (1 <= lens[b] <= L), speaker [n_spk_ids] int64 with
@@ -133,40 +151,40 @@ int e2etts_load_weights_bcast(e2etts_engine* engine, const void* blob_or_null, s
  * length, pitch_idx / energy_idx [B, L] int32 (the bucket indices of U/function.py:178-187 and
  * U/layers.py:169), log_dur [B, L], pitch_pred [B, L, 2] ([B, L] when pitch_no_uv), energy_pred [B, L].
  * mel / mel_post stay resident; read them with e2etts_fetch_mel.  One host sync (for T). */
-int e2etts_acoustic(e2etts_engine* engine, const int64_t* ids, const int64_t* lens, int B, int L,
+E2ETTS_API int e2etts_acoustic(e2etts_engine* engine, const int64_t* ids, const int64_t* lens, int B, int L,
                     const int64_t* speaker, int n_spk_ids, float d_control, float p_control, float e_control,
                     float* dur_out, int64_t* mel_lens_out, int* T_out, int32_t* pitch_idx_out, int32_t* energy_idx_out,
                     float* log_dur_out, float* pitch_pred_out, float* energy_pred_out);
 
 /* Copies of the resident results of the last e2etts_acoustic: mel, mel_post [B, T, n_mel] (either may be NULL). */
-int e2etts_fetch_mel(e2etts_engine* engine, float* mel, float* mel_post);
+E2ETTS_API int e2etts_fetch_mel(e2etts_engine* engine, float* mel, float* mel_post);
 
 /* Debug / parity taps of the last e2etts_acoustic: which = "enc_out" [B, L, H] | "dec_out" [B, T, H]. */
 /* taps: "enc_out" [B, L, hidden], "dec_out" [B, T, hidden] (after e2etts_acoustic); "istft_spec_phase" [B, T * prod(voc_up_rate) + 1,
  * n_fft + 2] = exp / sin heads of the iSTFTNet generator (reference iSTFT.forward's return values), after a vocoder call. */
-int e2etts_fetch_tap(e2etts_engine* engine, const char* which, float* out, size_t n_floats);
+E2ETTS_API int e2etts_fetch_tap(e2etts_engine* engine, const char* which, float* out, size_t n_floats);
 /* more taps of the last e2etts_acoustic, at the level the feature lives at (N = L for phoneme_level, T for frame_level):
  * e2etts_fetch_tap: "pitch_pred" [B, N, 2] ([B, N] when pitch_no_uv), "energy_pred" [B, N]; e2etts_fetch_tap_i32: "pitch_idx", "energy_idx" [B, N]. */
-int e2etts_fetch_tap_i32(e2etts_engine* engine, const char* which, int32_t* out, size_t n_values);
+E2ETTS_API int e2etts_fetch_tap_i32(e2etts_engine* engine, const char* which, int32_t* out, size_t n_values);
 
 /* Replaces: HifiGan.forward (V/generator.py:37-53) on mel [B, n_mel, T] (the reference layout,
  * channels-first, as API/utils.py:144 passes it) or, when mel == NULL, on the resident mel_post of the
  * last e2etts_acoustic.  Outputs (each may be NULL): wav [B, T*hop] fp32 in (-1, 1);
  * pcm [B, T*hop] int16 = trunc(wav * 32768) as TTS.combine_audio computes it (API/utils.py:111-117). */
-int e2etts_vocoder(e2etts_engine* engine, const float* mel_bct, int B, int T, float* wav_out, int16_t* pcm_out);
+E2ETTS_API int e2etts_vocoder(e2etts_engine* engine, const float* mel_bct, int B, int T, float* wav_out, int16_t* pcm_out);
 
 /* Same, mel given channels-last [B, T, n_mel] (the engine's native layout; no transpose). */
-int e2etts_vocoder_btc(e2etts_engine* engine, const float* mel_btc, int B, int T, float* wav_out, int16_t* pcm_out);
+E2ETTS_API int e2etts_vocoder_btc(e2etts_engine* engine, const float* mel_btc, int B, int T, float* wav_out, int16_t* pcm_out);
 
 /* Replaces one iteration of the TTS.inference batch loop (API/utils.py:130-148): acoustic -> vocoder.
  * pcm_out [B, T*hop] int16 (rows padded to the batch maximum; valid samples of row b = mel_lens[b]*hop),
  * mel_lens_out [B]. T_out receives T.  pcm_capacity = number of int16 the caller's buffer holds; if it is
  * too small E2ETTS_EINVAL is returned with T_out set, and the result can be fetched with e2etts_fetch_pcm. */
-int e2etts_synthesize(e2etts_engine* engine, const int64_t* ids, const int64_t* lens, int B, int L,
+E2ETTS_API int e2etts_synthesize(e2etts_engine* engine, const int64_t* ids, const int64_t* lens, int B, int L,
                       const int64_t* speaker, int n_spk_ids, float d_control, float p_control, float e_control,
                       int16_t* pcm_out, size_t pcm_capacity, int64_t* mel_lens_out, int* T_out);
-int e2etts_fetch_pcm(e2etts_engine* engine, int16_t* pcm_out, size_t capacity);
-int e2etts_fetch_wav(e2etts_engine* engine, float* wav_out, size_t capacity);
+E2ETTS_API int e2etts_fetch_pcm(e2etts_engine* engine, int16_t* pcm_out, size_t capacity);
+E2ETTS_API int e2etts_fetch_wav(e2etts_engine* engine, float* wav_out, size_t capacity);
 
 /* Long-form / streaming vocoder (BASELINE config 5).  The mel stream of B parallel utterances is pushed in chunks of any
  * size, channels-last [B, n, n_mel] (host or device memory); the engine keeps the receptive-field halo (returned by
@@ -175,9 +193,9 @@ int e2etts_fetch_wav(e2etts_engine* engine, float* wav_out, size_t capacity);
  *   _begin(B)                      -> halo in frames (>= 0) or a negative error
  *   _push(mel, n, last, &n_emit)   -> runs the vocoder on [context | pending | new]; n_emit frames became final
  *   _fetch(wav, pcm, capacity)     -> copies those n_emit * hop samples per utterance, [B, n_emit * hop] compact */
-int e2etts_vocoder_stream_begin(e2etts_engine* engine, int B);
-int e2etts_vocoder_stream_push(e2etts_engine* engine, const float* mel_btc, int n_frames, int last, int* n_frames_out);
-int e2etts_vocoder_stream_fetch(e2etts_engine* engine, float* wav_out, int16_t* pcm_out, size_t capacity);
+E2ETTS_API int e2etts_vocoder_stream_begin(e2etts_engine* engine, int B);
+E2ETTS_API int e2etts_vocoder_stream_push(e2etts_engine* engine, const float* mel_btc, int n_frames, int last, int* n_frames_out);
+E2ETTS_API int e2etts_vocoder_stream_fetch(e2etts_engine* engine, float* wav_out, int16_t* pcm_out, size_t capacity);
 
 /* Replaces: audio_speed_change (API/utils.py:163-172), which shells out to ffmpeg's `atempo` filter: tempo change without pitch change
  * of an int16 PCM signal (host or device memory), on the GPU.  ffmpeg is not part of this build: the kernel is waveform-similarity
@@ -188,7 +206,7 @@ int e2etts_vocoder_stream_fetch(e2etts_engine* engine, float* wav_out, int16_t* 
 /* `speed` is a double: n_out and the per-frame analysis positions are computed from it exactly as the Python mirror computes them from
  * its float (a C float 0.8f is 0.800000012, which rounds n_in / speed the other way at exact .5 ties).  sample_rate in [4000, 96000]: the
  * kernel keeps one analysis frame, its search region and three work frames in LDS (0.18 s of float64 samples <= 160 KB). */
-int e2etts_tempo(e2etts_engine* engine, const int16_t* pcm_in, size_t n_in, double speed, int sample_rate, int16_t* pcm_out,
+E2ETTS_API int e2etts_tempo(e2etts_engine* engine, const int16_t* pcm_in, size_t n_in, double speed, int sample_rate, int16_t* pcm_out,
                  size_t capacity, size_t* n_out);
 
 /* Arithmetic of the convolutions / projections of (a) the vocoder and (b) the decoder + mel_linear + postnet.
@@ -203,7 +221,7 @@ int e2etts_tempo(e2etts_engine* engine, const int16_t* pcm_in, size_t n_in, doub
 #define E2ETTS_PRECISION_BF16X3 1
 #define E2ETTS_PRECISION_BF16 2 /* vocoder only: hi x hi product alone (plain bf16 operands, fp32 accumulation): the arithmetic
                                    BASELINE config 5 (long-form streaming) names; waveform error ~5e-4, above the fp32 bar */
-int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decoder_precision);
+E2ETTS_API int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decoder_precision);
 
 /* Ragged batches (default on).  e2etts_synthesize hands back, per utterance, only mel_lens[b] * hop valid samples; with
  * ragged != 0 it therefore skips, layer by layer, the rows of shorter utterances that no valid sample depends on (rows past
@@ -214,18 +232,22 @@ int e2etts_set_precision(e2etts_engine* engine, int vocoder_precision, int decod
  * predictors) additionally when `lens` is HOST memory (the launch grids are built from the lengths on the host; with `lens` in device
  * memory the phoneme level computes the padded batch -- same results).  Batches of up to 64 utterances launch grids without idle
  * workgroups; larger ones still skip the rows but keep the padded grid. */
-int e2etts_set_ragged(e2etts_engine* engine, int enable);
+E2ETTS_API int e2etts_set_ragged(e2etts_engine* engine, int enable);
 
-/* Test hook for ragged mode: overwrite the activation workspaces (not the weights, not the index buffers) with a large finite pattern
- * (every byte 0x4B: 1.3e7 as fp32), so that a test can show that no valid sample of the next call depends on what an earlier call left
- * in the rows that ragged compute skips.  No effect on results by construction; nothing in the product path calls it. */
-int e2etts_debug_poison_workspace(e2etts_engine* engine);
+/* Test hook for ragged mode, present only in the TEST build of the library (compiled with -DE2ETTS_TEST_HOOKS into
+ * libe2etts_hip_test.so; the product library libe2etts_hip.so does not export it): overwrite the activation workspaces (not the
+ * weights, not the index buffers) with a large finite pattern (every byte 0x4B: 1.3e7 as fp32) and forget the resident results, so
+ * that a test can show that no valid sample of the next call depends on what an earlier call left in the rows that ragged compute
+ * skips. */
+#ifdef E2ETTS_TEST_HOOKS
+E2ETTS_API int e2etts_debug_poison_workspace(e2etts_engine* engine);
+#endif
 
 /* Fused ResBlocks (bf16 modes).  level 1: each (conv k, dilation d -> leaky ReLU -> conv k -> + x) pair of HiFi-GAN's ResBlock1
  * (reference V/layers.py:33-40) at 32 / 64 / 128 / 256 channels runs as ONE kernel whose intermediate stays in LDS.  level 2
  * (default): additionally a whole kernel-size-3 ResBlock1 (its three pairs) at 32 / 64 channels runs as one kernel whose residual
  * stream stays in registers.  level 0: two convolution launches per pair.  All three produce bit-identical output. */
-int e2etts_set_fused_resblocks(e2etts_engine* engine, int level);
+E2ETTS_API int e2etts_set_fused_resblocks(e2etts_engine* engine, int level);
 
 /* Per-kernel-class timing with HIP events on the engine's stream (bench.py roofline leg).
  * enable != 0 starts recording (and clears counters); e2etts_profile_read fills up to `cap` records. */
@@ -238,20 +260,20 @@ typedef struct e2etts_kernel_stat {
 } e2etts_kernel_stat;
 /* Restrict the event bracketing to one kernel class (NULL or "": all classes).  Two hipEventRecord per launch cost ~8 us; with ~155
  * launches per step that is 2 % of a step, so a timed region that only needs the dominant kernel's duration brackets that class alone. */
-int e2etts_profile_filter(e2etts_engine* engine, const char* kernel_class);
-int e2etts_profile_enable(e2etts_engine* engine, int enable);
-int e2etts_profile_read(e2etts_engine* engine, e2etts_kernel_stat* out, int cap);
+E2ETTS_API int e2etts_profile_filter(e2etts_engine* engine, const char* kernel_class);
+E2ETTS_API int e2etts_profile_enable(e2etts_engine* engine, int enable);
+E2ETTS_API int e2etts_profile_read(e2etts_engine* engine, e2etts_kernel_stat* out, int cap);
 
 /* Bytes of HBM currently owned by the engine (weights + workspace). */
-size_t e2etts_device_bytes(const e2etts_engine* engine);
+E2ETTS_API size_t e2etts_device_bytes(const e2etts_engine* engine);
 
 /* The engine's stream as a hipStream_t cast to void* (so a caller can order its own work after ours). */
-void* e2etts_stream(e2etts_engine* engine);
+E2ETTS_API void* e2etts_stream(e2etts_engine* engine);
 /* Orders everything the engine does from now on after the work queued so far on `caller_stream` (a hipStream_t cast to
  * void*; NULL = the legacy default stream): an event recorded there, waited for on the engine's stream.  See "STREAM
  * ORDERING" at the top.  Costs two API calls, no host synchronisation. */
-int e2etts_order_after(e2etts_engine* engine, void* caller_stream);
-int e2etts_sync(e2etts_engine* engine);
+E2ETTS_API int e2etts_order_after(e2etts_engine* engine, void* caller_stream);
+E2ETTS_API int e2etts_sync(e2etts_engine* engine);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
+# The tests load the TEST build of the library (libe2etts_hip_test.so: the product sources + the e2etts_debug_poison_workspace hook that the
+# ragged-mode tests need); child processes inherit the choice.  tests/test_gpu_dropin.py: test_product_library_gives_the_test_builds_bits
+# runs the product library next to it.
+os.environ.setdefault("E2ETTS_TEST_HOOKS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

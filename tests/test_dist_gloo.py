@@ -218,6 +218,52 @@ def test_bench_rank_failure_is_reported_by_the_launcher():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "no CPU fallback" in r.stderr
+    # the launcher names the rank that failed first and repeats its last stderr line
+    assert "failed first (exit code" in r.stderr and "its last stderr line: bench.py needs a GPU" in r.stderr
+
+
+def test_bench_called_plainly_with_gpus_8_under_gloo():
+    """The N = 8 shape of the driver's scaling run, rehearsed here with the stand-in engine over gloo (the driver's own N = 8 run needs an
+    8-GPU node): eight self-launched ranks, one JSON line, whole-job aggregate over all eight, the config-4 list dealt evenly."""
+    d = _run_bench_plainly("--gpus", "8", "--steps", "2", "--warmup", "1")
+    assert d["data"] == "stub" and d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "utterance-sharded x8"
+    samples = 8 * 32 * 768 * 256
+    assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    c4 = d["c4_sharded"]
+    assert c4["utterances"] == 256 and c4["ranks"] == 8 and len(c4["frames_per_rank"]) == 8 and c4["batches_per_rank"] == 1
+    assert 1.0 <= c4["balance_max_over_mean"] <= 1.01
+
+
+def test_collectives_default_to_the_groups_device(monkeypatch):
+    """`synthesize_sharded(engine, id_lists, ...)` -- the documented call, device=None -- must build its collective
+    tensors where the process group can move them: on this process's cuda device under backend "nccl" (RCCL has no CPU tensors), on the
+    host under gloo or without a group.  The backend query is patched: no RCCL group exists on a CPU box."""
+    import torch
+    import torch.distributed as dist
+    assert edist._collective_device(None) == torch.device("cpu")            # no group
+    assert edist._collective_device("cpu") == torch.device("cpu")
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_backend", lambda *a, **k: "gloo")
+    assert edist._collective_device(None) == torch.device("cpu")
+    monkeypatch.setattr(dist, "get_backend", lambda *a, **k: "nccl")
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 3)
+    assert edist._collective_device(None) == torch.device("cuda", 3)
+    assert edist._collective_device("cuda:1") == torch.device("cuda", 1)    # an explicit device wins
+
+
+def test_gather_pcm_validates_before_any_collective(monkeypatch):
+    """a rank holding a bad (index, PCM) entry must raise BEFORE the first collective, not between two of them (the other
+    ranks would wait in the next one).  Every collective is patched to fail the test if it is reached."""
+    import pytest
+    import torch.distributed as dist
+    monkeypatch.setattr(edist, "_world_rank", lambda: (2, 0))
+    for name in ("all_reduce", "all_gather", "gather"):
+        monkeypatch.setattr(dist, name, lambda *a, _n=name, **k: pytest.fail(f"dist.{_n} reached before validation"))
+    with pytest.raises(TypeError, match="utterance 1"):
+        edist.gather_pcm([(0, np.zeros(4, np.int16)), (1, np.zeros(4, np.float32))])
+    with pytest.raises(TypeError, match="utterance 0"):
+        edist.gather_pcm([(0, np.zeros((2, 2), np.int16))])
 
 
 def test_bench_workload_c4_world2():

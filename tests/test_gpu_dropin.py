@@ -348,3 +348,46 @@ def test_gather_pcm_tensor_path_over_rccl_single_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
+
+
+_PRODUCT_CHILD = r"""
+import hashlib, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from e2e_tts_amd import _lib, config as cfgmod, synth_weights as sw
+from e2e_tts_amd.runtime import engine_from_states
+lib = _lib.load_library()
+assert os.path.basename(lib._name) == sys.argv[3], lib._name
+cfg = cfgmod.tiny_config(); stats = cfgmod.DEFAULT_STATS
+ac = sw.make_acoustic_state(cfg, stats, 4, seed=1234, mode="varied"); voc = sw.make_vocoder_state(cfg, seed=4321)
+eng = engine_from_states(cfg, stats, ac, voc, device=0)
+g = np.load(sys.argv[2])
+pcm, mel_lens, T = eng.synthesize(g["ids"], g["lens"], np.array([int(g["speaker"])], np.int64))
+try:
+    eng.poison_workspace()
+    hook = "hook"
+except RuntimeError:
+    hook = "nohook"
+print("PCM_SHA", hashlib.sha256(np.ascontiguousarray(pcm).tobytes()).hexdigest(), T, hook)
+"""
+
+
+@pytest.mark.gpu
+def test_product_library_gives_the_test_builds_bits(tmp_path):
+    """The GPU tests load libe2etts_hip_test.so (E2ETTS_TEST_HOOKS=1, tests/conftest.py): the product sources plus ONE more export.  This
+    runs the same utterances through both libraries in child processes -- the product one must refuse the hook and give the same PCM
+    bit for bit, so what the suite proves about the test build holds for the library a host links."""
+    import subprocess
+    import sys
+    from conftest import GOLD, ROOT
+    script = tmp_path / "product_child.py"
+    script.write_text(_PRODUCT_CHILD)
+    outs = []
+    for hooks, name, want in (("0", "libe2etts_hip.so", "nohook"), ("1", "libe2etts_hip_test.so", "hook")):
+        env = dict(os.environ, E2ETTS_TEST_HOOKS=hooks)
+        r = subprocess.run([sys.executable, str(script), ROOT, os.path.join(GOLD, "tiny_b3.npz"), name], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "PCM_SHA" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("PCM_SHA")][0].split()
+        assert line[3] == want, line
+        outs.append(line[1:3])
+    assert outs[0] == outs[1]

@@ -88,6 +88,9 @@ struct e2etts_engine {
   // split-precision image -> the same weights in MFMA-fragment order (built on the device at load time for the layers
   // the 128-column kernel serves: their waves read weight fragments straight from L2, no LDS tile, no barrier per tap)
   std::map<const float*, float*> frag_of;
+  // split-precision image -> its hi halves in conv_bf16.hip's order (launch_bf16_image), for the vocoder's plain-bf16 mode; value: image
+  // and the tap_split it was built with (polyphase upsamplers keep two taps per 32-column tile)
+  std::map<const float*, std::pair<void*, int>> bimg_of;
   size_t frag_bytes = 0;
   bool ac_loaded = false, voc_loaded = false;
   std::vector<FFTLayer> enc, dec;
@@ -264,6 +267,24 @@ int prof_collect(e2etts_engine* e) {
     if (_m) return (e)->fail(E2ETTS_EINVAL, "%s", _m);             \
   } while (0)
 
+// The plain-bf16 mode's convolutions on conv_bf16.hip (bit-identical to conv_gemm's mode 2, so the choice is per launch): a padded
+// batch, dense rows, an activation that is a slope.  E2ETTS_BCONV=0 (tuning aid) keeps them on conv_gemm.
+bool bconv_params(const ConvParams& p, BConvParams& q) {
+  static const bool on = !(getenv("E2ETTS_BCONV") && atoi(getenv("E2ETTS_BCONV")) == 0);
+  if (!on || p.x3 != 2 || !p.bimg || p.act_rows || p.lens) return false;
+  if (p.act != ACT_NONE && p.act != ACT_RELU && p.act != ACT_LRELU) return false;
+  if (p.in_ld != p.Cin || p.out_ld != p.Cout || (p.res && p.res_ld != p.Cout)) return false;
+  if (p.in_bs != (long long)p.T * p.Cin || p.out_bs != (long long)p.T * p.Cout || (p.res && p.res_bs != p.out_bs)) return false;
+  if (p.bimg_tap_split != p.zero_tap_split) return false;
+  q = BConvParams();
+  q.in = p.in; q.in_bf16 = p.in_bf16; q.in_slope = p.in_slope; q.wimg = p.bimg; q.tap_split = p.bimg_tap_split;
+  q.KWe = p.bimg_tap_split > 0 ? 2 : p.KW;
+  q.bias = p.bias; q.act_slope = p.act == ACT_LRELU ? p.act_slope : (p.act == ACT_RELU ? 0.f : 1.f);
+  q.res = p.res; q.accumulate = p.accumulate; q.out_div = p.out_div; q.out = p.out; q.out_b = p.out_b; q.outb_slope = p.outb_slope;
+  q.B = p.B; q.T = p.T; q.Cin = p.Cin; q.Cout = p.Cout; q.KW = p.KW; q.dil = p.dil; q.pad = p.pad;
+  return conv_bf16_supported(q);
+}
+
 // One conv / linear launch.  alg_scale < 1 when part of the packed weight is structural zeros
 // (the polyphase upsampler) so that the recorded FLOPs stay the algorithmic ones.
 // ksplit: a phoneme-level layer (encoder FFT blocks, predictors): served by conv_ksplit.hip at every batch size when its fp32 fragment
@@ -285,6 +306,15 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0, bool ksplit = f
   if (fine && e->prof_on)
     snprintf(fname, sizeof fname, "%s %d>%d k%d d%d r%lld%s%s", p.x3 ? "x3" : "f32", p.Cin, p.Cout, p.KW, p.dil,
              (long long)p.B * p.T, p.res ? "+r" : "", p.accumulate ? "+a" : "");
+  {
+    BConvParams q;
+    if (bconv_params(p, q)) {
+      ProfScope ps(e, fine && e->prof_on ? fname : conv_bf16_class(q), conv_gemm_flops(p) * alg_scale, conv_gemm_bytes(p));
+      KCHK(e, launch_conv_bf16(q, e->stream));
+      return E2ETTS_OK;
+    }
+    if (p.in_bf16 || p.out_b) return e->fail(E2ETTS_EINVAL, "bf16 hand-over asked of a launch conv_bf16 does not serve");
+  }
   static const bool ksplit_on = !(getenv("E2ETTS_KSPLIT") && atoi(getenv("E2ETTS_KSPLIT")) == 0);
   // ... and only where the chain is long (K = KW x Cin >= 768: the FFN convolutions, the predictors): a q | k | v or fc projection
   // (K = 384) is a chain of 12 short links, and at B = 32 the split costs those more (three idle waves per epilogue) than it saves.
@@ -316,6 +346,8 @@ void free_frags(e2etts_engine* e) {
     (void)hipFree(kv.second);
   }
   e->frag_of.clear();
+  for (auto& kv : e->bimg_of) (void)hipFree(kv.second.first);
+  e->bimg_of.clear();
   for (float* f : e->rb_frag_base)
     if (f) (void)hipFree(f);
   e->rb_frag_base.clear();
@@ -350,6 +382,20 @@ int make_frag32(e2etts_engine* e, const float* w, uint64_t cout, uint64_t kw, ui
   e->frag_bytes += bytes;
   e->frag_of[w] = f;
   KCHK(e, launch_f32_to_frag(w, f, (int)cout, (int)kw, (int)cin, e->stream));
+  return E2ETTS_OK;
+}
+
+// hi halves of a vocoder convolution's split-precision image in conv_bf16.hip's order (plain-bf16 mode).  tap_split: see BConvParams.
+int make_bimg(e2etts_engine* e, const float* wx3, uint64_t cout, uint64_t kw, uint64_t cin, int tap_split = 0) {
+  if (!wx3 || (cout % 32) || e->bimg_of.count(wx3)) return E2ETTS_OK;
+  if (tap_split > 0 && (kw != 3 || (tap_split % 32))) tap_split = 0;   // no polyphase image: the kernel multiplies the zeros
+  void* img = nullptr;
+  const size_t bytes = bf16_image_bytes((int)cout, (int)kw, (int)cin, tap_split);
+  HIPCHK(e, hipMalloc(&img, bytes));
+  e->dev_bytes += bytes;
+  e->frag_bytes += bytes;
+  e->bimg_of[wx3] = {img, tap_split};
+  KCHK(e, launch_bf16_image(wx3, img, (int)cout, (int)kw, (int)cin, tap_split, e->stream));
   return E2ETTS_OK;
 }
 
@@ -542,6 +588,7 @@ int bind_vocoder(e2etts_engine* e) {
   const auto& c = e->cfg;
   const uint64_t C0 = c.voc_init_ch;
   RET(bind_conv(e, "voc.pre", C0, 7, c.n_mel, e->voc_pre));
+  RET(make_bimg(e, e->voc_pre.wx3, C0, 7, c.n_mel));
   e->voc_up.resize(c.voc_stages);
   e->rb_c1.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
   e->rb_c2.assign((size_t)c.voc_stages * c.voc_n_kernels, {});
@@ -554,6 +601,7 @@ int bind_vocoder(e2etts_engine* e) {
     RET(bind_conv(e, "voc.up." + std::to_string(i), s * cout, 3, cin, e->voc_up[i]));
     // the last upsampler of HiFi-GAN V1 (64 columns), exact fp32: fragments for the zero-tap-skipping 256 x 32 tile (conv_gemm.hip)
     if (s * cout == 64) RET(make_frag32(e, e->voc_up[i].w, s * cout, 3, cin, true));
+    RET(make_bimg(e, e->voc_up[i].wx3, s * cout, 3, cin, (int)(s * cout / 2)));
     ch = cout;
     for (int j = 0; j < c.voc_n_kernels; ++j) {
       const int idx = i * c.voc_n_kernels + j;
@@ -568,6 +616,8 @@ int bind_vocoder(e2etts_engine* e) {
         }
         RET(bind_conv(e, q + "c1." + std::to_string(m), ch, k, ch, e->rb_c1[idx][m]));
         RET(bind_conv(e, q + "c2." + std::to_string(m), ch, k, ch, e->rb_c2[idx][m]));
+        RET(make_bimg(e, e->rb_c1[idx][m].wx3, ch, k, ch));
+        RET(make_bimg(e, e->rb_c2[idx][m].wx3, ch, k, ch));
       }
     }
     // fused pairs: all of a stage or none (the two forms use the stage's scratch buffers differently)
@@ -1097,6 +1147,10 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     q.bias = w.b;
     if (e->voc_precision != E2ETTS_PRECISION_FP32 && w.wx3) { q.w = w.wx3; q.x3 = e->voc_precision; }
     else { q.w = w.w; q.x3 = 0; }
+    if (q.x3 == E2ETTS_PRECISION_BF16) {   // plain bf16: the same weights in conv_bf16.hip's order (the router in conv() decides)
+      auto it = e->bimg_of.find(w.wx3);
+      if (it != e->bimg_of.end()) { q.bimg = it->second.first; q.bimg_tap_split = it->second.second; }
+    }
   };
   // Ragged mode: the layers of stage i compute rows < mel_len * rate_i + halo_i only (host_logic.h: vocoder_stage_halo_rows -- the
   // reach of what is still to come, in that stage's rows: 12 frames after conv_pre, 76 / 109 / 94 / 63 rows in the four stages of
@@ -1142,7 +1196,15 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   // (a profile of ALL classes wants one kernel at a time; a profile filtered to one class -- bench.py's timed region -- records its
   // events on whichever stream the launch goes to and is fine)
   const bool full_profile = e->prof_on && e->prof_filter.empty();
-  const bool conc = !full_profile && nk > 1 && nk <= E2ETTS_MAX_RB_KERNELS && (long long)B * T <= conc_frames;
+  // Plain bf16 at such sizes goes one step further (conv_bf16.hip: launch_*_group): pair m of ALL ResBlocks of the stage is ONE launch on
+  // the engine's stream -- a third of the launches, no fork / join events, and a grid the three kernel sizes fill together (one ResBlock's
+  // pair is 1.15 rounds of workgroups at a 542-frame window, the k = 11 stream the critical path of every stage, and the host needed
+  // longer to enqueue three streams' launches than the GPU to run them).  Each ResBlock keeps its own buffers as on the side streams,
+  // and the join below is the same: same bits.  E2ETTS_VOC_GROUP=0 (tuning aid) keeps the streams.
+  static const bool group_env = !(getenv("E2ETTS_VOC_GROUP") && atoi(getenv("E2ETTS_VOC_GROUP")) == 0);
+  const bool small_window = nk > 1 && nk <= E2ETTS_MAX_RB_KERNELS && nk <= BC_GROUP_MAX && (long long)B * T <= conc_frames;
+  const bool group_mode = group_env && small_window && e->voc_precision == E2ETTS_PRECISION_BF16 && !ragged_lens && c.voc_resblock == 1 && e->fuse_pairs;
+  const bool conc = (!full_profile || group_mode) && nk > 1 && nk <= E2ETTS_MAX_RB_KERNELS && (long long)B * T <= conc_frames;
   if (conc) {
     for (int j = 0; j + 1 < nk; ++j) {
       if (!e->side[j]) HIPCHK(e, hipStreamCreateWithFlags(&e->side[j], hipStreamNonBlocking));
@@ -1182,7 +1244,95 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     n *= s;
     ch = co;
     if (n > 0x7fffffffLL / 2) return e->fail(E2ETTS_EINVAL, "utterance too long");
-    if (conc) {  // fork: the side streams may start once the upsampler's output (and everything before it) is complete
+    // ---- grouped launches (see group_mode above): pair m of every ResBlock in one launch; at 256 channels, where a pair runs as two
+    // convolutions with a bf16 hand-over, conv1 of every ResBlock and then conv2 of every ResBlock
+    bool grouped_stage = false;
+    if (group_mode) {
+      float* Sj[E2ETTS_MAX_RB_KERNELS]; float* T1j[E2ETTS_MAX_RB_KERNELS]; float* CURj[E2ETTS_MAX_RB_KERNELS];
+      int order[E2ETTS_MAX_RB_KERNELS];   // dispatch order inside a launch: largest kernel size first
+      for (int j = 0; j < nk; ++j) {
+        Sj[j] = j ? ptr<float>(e->vside[j - 1][0]) : S; T1j[j] = j ? ptr<float>(e->vside[j - 1][1]) : T1; CURj[j] = j ? ptr<float>(e->vside[j - 1][2]) : CUR;
+        order[j] = j;
+      }
+      std::sort(order, order + nk, [&](int a, int b2) { return c.voc_rb_kernel[a] > c.voc_rb_kernel[b2]; });
+      const bool as_pairs = co <= 128;
+      // every member of every launch must be servable: decided before anything is launched
+      bool ok = true;
+      for (int j = 0; j < nk && ok; ++j)
+        for (int m = 0; m < c.voc_n_dil && ok; ++m) {
+          const int idx = i * nk + j;
+          auto i1 = e->bimg_of.find(e->rb_c1[idx][m].wx3), i2 = e->bimg_of.find(e->rb_c2[idx][m].wx3);
+          ok = i1 != e->bimg_of.end() && i2 != e->bimg_of.end();
+          if (!ok) break;
+          if (as_pairs) {
+            PairParams q;
+            q.x = XU; q.out = Sj[j]; q.b1 = e->rb_c1[idx][m].b; q.b2 = e->rb_c2[idx][m].b; q.bimg1 = i1->second.first; q.bimg2 = i2->second.first;
+            q.B = B; q.T = (int)n; q.C = co; q.KW = c.voc_rb_kernel[j]; q.dil = c.voc_rb_dil[j][m]; q.x_bs = q.out_bs = (long long)n * co; q.mode = 2;
+            ok = pair_bf16_supported(q);
+          } else {
+            BConvParams q;
+            q.in = XU; q.wimg = i1->second.first; q.KWe = q.KW = c.voc_rb_kernel[j]; q.dil = c.voc_rb_dil[j][m]; q.pad = (q.KW * q.dil - q.dil) / 2;
+            q.out_b = T1j[j]; q.B = B; q.T = (int)n; q.Cin = q.Cout = co;
+            ok = conv_bf16_supported(q);
+          }
+        }
+      if (ok) {
+        grouped_stage = true;
+        const float* curj[E2ETTS_MAX_RB_KERNELS];
+        for (int j = 0; j < nk; ++j) curj[j] = XU;
+        for (int m = 0; m < c.voc_n_dil; ++m) {
+          const bool last = m == c.voc_n_dil - 1;
+          if (as_pairs) {
+            PairParams qs[E2ETTS_MAX_RB_KERNELS];
+            double fl = 0, by = 0;
+            for (int t = 0; t < nk; ++t) {
+              const int j = order[t], idx = i * nk + j;
+              PairParams& q = qs[t];
+              q = PairParams();
+              q.x = curj[j]; q.b1 = e->rb_c1[idx][m].b; q.b2 = e->rb_c2[idx][m].b;
+              q.bimg1 = e->bimg_of[e->rb_c1[idx][m].wx3].first; q.bimg2 = e->bimg_of[e->rb_c2[idx][m].wx3].first;
+              q.out = last ? Sj[j] : (curj[j] == CURj[j] ? T1j[j] : CURj[j]);   // x and out must differ: the running x ping-pongs CUR / T1
+              q.B = B; q.T = (int)n; q.C = co; q.KW = c.voc_rb_kernel[j]; q.dil = c.voc_rb_dil[j][m];
+              q.x_bs = q.out_bs = (long long)n * co; q.slope = 0.1f; q.mode = 2;
+              fl += resblock_pair_flops(q); by += resblock_pair_bytes(q);
+            }
+            char nm[48];
+            snprintf(nm, sizeof nm, "pair_bf16_group_%d", co);
+            ProfScope ps(e, nm, fl, by);
+            KCHK(e, launch_pair_bf16_group(qs, nk, e->stream));
+            for (int t = 0; t < nk; ++t) curj[order[t]] = qs[t].out;
+          } else {
+            BConvParams q1[E2ETTS_MAX_RB_KERNELS], q2[E2ETTS_MAX_RB_KERNELS];
+            double fl = 0, by = 0;
+            for (int t = 0; t < nk; ++t) {
+              const int j = order[t], idx = i * nk + j;
+              const int k = c.voc_rb_kernel[j], d = c.voc_rb_dil[j][m];
+              BConvParams& a = q1[t];   // xt = lrelu(c1(lrelu(x)) + b1), handed over as conv2's bf16 operand (V/layers.py:35-38)
+              a = BConvParams();
+              a.in = curj[j]; a.in_slope = 0.1f; a.wimg = e->bimg_of[e->rb_c1[idx][m].wx3].first; a.KWe = a.KW = k; a.dil = d; a.pad = (k * d - d) / 2;
+              a.bias = e->rb_c1[idx][m].b; a.act_slope = 0.1f; a.out_b = T1j[j]; a.B = B; a.T = (int)n; a.Cin = a.Cout = co;
+              BConvParams& z = q2[t];   // x = c2(xt) + x (:38-39)
+              z = BConvParams();
+              z.in = T1j[j]; z.in_bf16 = 1; z.wimg = e->bimg_of[e->rb_c2[idx][m].wx3].first; z.KWe = z.KW = k; z.dil = 1; z.pad = (k - 1) / 2;
+              z.bias = e->rb_c2[idx][m].b; z.res = curj[j]; z.out = last ? Sj[j] : CURj[j]; z.B = B; z.T = (int)n; z.Cin = z.Cout = co;
+              fl += 2.0 * B * (double)n * co * k * co; by += 4.0 * ((double)B * n * co * 2.0 + (double)co * k * co);
+            }
+            char nm[48];
+            snprintf(nm, sizeof nm, "conv_bf16_group_%d", co);
+            {
+              ProfScope ps(e, nm, fl, by);
+              KCHK(e, launch_conv_bf16_group(q1, nk, e->stream));
+            }
+            {
+              ProfScope ps(e, nm, fl, by * 1.5);
+              KCHK(e, launch_conv_bf16_group(q2, nk, e->stream));
+            }
+            for (int t = 0; t < nk; ++t) curj[order[t]] = q2[t].out;
+          }
+        }
+      }
+    }
+    if (conc && !grouped_stage) {  // fork: the side streams may start once the upsampler's output (and everything before it) is complete
       HIPCHK(e, hipEventRecord(e->ev_fork, main_stream));
       drain.armed = true;
       for (int j = 0; j + 1 < nk; ++j) HIPCHK(e, hipStreamWaitEvent(e->side[j], e->ev_fork, 0));
@@ -1190,7 +1340,12 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     float* const S_main = S;
     float* const T1_main = T1;
     float* const CUR_main = CUR;
-    for (int j = 0; j < c.voc_n_kernels; ++j) {
+    // Side by side, the ResBlocks are ENQUEUED last one first: at small windows (a 542-frame streaming window's 256-channel stage: six
+    // launches of ~15 us per ResBlock) the host needs longer to enqueue a ResBlock's launches than the GPU to run them, so the stream
+    // enqueued last starts late by the others' enqueue time -- and the last ResBlock has the largest kernel size, the stage's critical
+    // path.  Which stream a ResBlock runs on, and every result bit, are unchanged.
+    for (int jj = 0; jj < c.voc_n_kernels && !grouped_stage; ++jj) {
+      const int j = conc ? c.voc_n_kernels - 1 - jj : jj;
       const int idx = i * c.voc_n_kernels + j;
       const int k = c.voc_rb_kernel[j];
       // this ResBlock's stream and buffers (shadowing the stage-wide names below)
@@ -1246,8 +1401,14 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
           char nm[48];
           if (fine) snprintf(nm, sizeof nm, "pair %d k%d d%d r%lld%s", co, k, q.dil, (long long)B * n, q.accumulate ? "+a" : "");
           else snprintf(nm, sizeof nm, f32 ? "resblock_pair_f32_%d" : "resblock_pair_%d", co);
+          if (q.mode == E2ETTS_PRECISION_BF16) {   // plain bf16: the same pair on conv_bf16.hip's machinery where it applies (same bits)
+            auto i1 = e->bimg_of.find(e->rb_c1[idx][m].wx3), i2 = e->bimg_of.find(e->rb_c2[idx][m].wx3);
+            if (i1 != e->bimg_of.end() && i2 != e->bimg_of.end()) { q.bimg1 = i1->second.first; q.bimg2 = i2->second.first; }
+          }
+          const bool bpair = pair_bf16_supported(q);
+          if (bpair && !fine) snprintf(nm, sizeof nm, "pair_bf16_%d", co);
           ProfScope ps(e, nm, resblock_pair_flops(q), resblock_pair_bytes(q));
-          KCHK(e, launch_resblock_pair(q, e->stream));
+          KCHK(e, bpair ? launch_pair_bf16(q, e->stream) : launch_resblock_pair(q, e->stream));
         }
         cur = q.out;
       }
@@ -1273,12 +1434,25 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         p = ConvParams();
         p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vfs[i + 1]; p.in = cur; setw(p, e->rb_c1[idx][m]); p.out = T1; p.Cin = co; p.Cout = co;
         p.KW = k; p.dil = d; p.pad = (k * d - d) / 2; p.in_slope = 0.1f; p.act = ACT_LRELU; p.act_slope = 0.1f;
+        // plain bf16 on conv_bf16.hip: xt is only ever read as conv2's bf16 operand, so conv1 writes THAT (2 bytes per element, rounded
+        // once, here) and conv2 copies it into its slab -- the values conv2's staging would have formed from an fp32 xt
+        bool handover = false;
+        {
+          ConvParams p2 = ConvParams();
+          p2.B = B; p2.T = (int)n; p2.in = T1; setw(p2, e->rb_c2[idx][m]); p2.res = cur; p2.out = CUR; p2.Cin = co; p2.Cout = co; p2.KW = k; p2.pad = (k - 1) / 2;
+          p2.in_ld = p2.out_ld = p2.res_ld = co; p2.in_bs = p2.out_bs = p2.res_bs = (long long)n * co;
+          ConvParams p1 = p; p1.in_ld = p1.out_ld = co; p1.in_bs = p1.out_bs = (long long)n * co;
+          BConvParams q1, q2;
+          handover = !p.act_rows && bconv_params(p1, q1) && bconv_params(p2, q2);
+        }
+        if (handover) { p.out = nullptr; p.out_b = T1; p.outb_slope = 1.0f; }
         RET(conv(e, p));
         // x = c2(xt) + x (:38-39); the last pair adds into the stage sum, and the last ResBlock divides by num_kernels
         // (V/generator.py:44-48)
         const bool last = m == c.voc_n_dil - 1;
         p = ConvParams();
         p.B = B; p.T = (int)n; p.act_rows = act_stage[i + 1]; p.act_rows_host = act_stage_h[i + 1]; p.act_frac = vfs[i + 1]; p.in = T1; setw(p, e->rb_c2[idx][m]); p.res = cur; p.Cin = co; p.Cout = co;
+        p.in_bf16 = handover ? 1 : 0;
         p.KW = k; p.dil = 1; p.pad = (k - 1) / 2;
         if (last) {
           p.out = S;
@@ -1293,7 +1467,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       if (aside) HIPCHK(e, hipEventRecord(e->ev_join[j - 1], e->stream));
     }
     if (conc) {  // join: S = ((S_0 + S_1) + S_2 ...) / num_kernels, the accumulating epilogues' order
-      for (int j = 1; j < nk; ++j) HIPCHK(e, hipStreamWaitEvent(main_stream, e->ev_join[j - 1], 0));
+      for (int j = 1; j < nk && !grouped_stage; ++j) HIPCHK(e, hipStreamWaitEvent(main_stream, e->ev_join[j - 1], 0));
       for (int j = 1; j < nk; j += 2) {  // two side sums per pass: (S + S_j) + S_j+1, the same additions in the same order
         const bool two = j + 1 < nk;
         const bool closes = (two ? j + 1 : j) == nk - 1;

@@ -63,6 +63,13 @@ struct ConvParams {
   float out_div = 1.0f;   // then value / out_div
   double act_frac = 1.0;  // host-side bookkeeping only: the fraction of the B x T rows that act_rows leaves to compute (ragged
                           // batches), so that conv_gemm_flops / _bytes count the work really done
+  // plain-bf16 mode of the vocoder (x3 == 2), used by the engine's router only (conv_gemm ignores them): the weights in conv_bf16.hip's
+  // order, and bf16 hand-over between two launches (the input given / the result also written as the bf16 image the next layer stages)
+  const void* bimg = nullptr;
+  int bimg_tap_split = 0;
+  int in_bf16 = 0;        // `in` points at bf16 [B, T, Cin]
+  void* out_b = nullptr;  // bf16(max(v, v * outb_slope)) [B, T, Cout]; `out` may then be null
+  float outb_slope = 1.0f;
 };
 // returns nullptr on success, else a static error string
 const char* launch_conv_gemm(const ConvParams& p, hipStream_t s);
@@ -148,8 +155,15 @@ struct PairParams {
   float out_div = 1.0f;          // then / out_div (needs accumulate)
   int mode = 1;                  // 0: exact fp32, 1: bf16x3 split precision, 2: plain bf16
   double act_frac = 1.0;         // host-side bookkeeping only (see ConvParams::act_frac)
+  const void* bimg1 = nullptr;   // mode 2, optional: conv1's and conv2's weights in conv_bf16.hip's order (launch_bf16_image): the pair then
+  const void* bimg2 = nullptr;   // may run on launch_pair_bf16 (same bits as launch_resblock_pair in mode 2)
 };
 bool resblock_pair_supported(int C, int KW, int dil);
+// the same pair in plain bf16 on conv_bf16.hip's machinery (whole-slab staging, ring-prefetched weights, 128 x 32 wavefront tiles);
+// padded batches (act_rows == null), C = 32 / 64 / 128
+bool pair_bf16_supported(const PairParams& p);
+const char* launch_pair_bf16(const PairParams& p, hipStream_t s);
+const char* launch_pair_bf16_group(const PairParams* p, int n, hipStream_t s);   // as launch_conv_bf16_group: same B, T, C; KW / dil / buffers per member
 const char* launch_resblock_pair(const PairParams& p, hipStream_t s);
 double resblock_pair_flops(const PairParams& p);
 double resblock_pair_bytes(const PairParams& p);
@@ -177,6 +191,49 @@ bool resblock_chain_supported(int C, int KW, const int* dil, int n_dil);
 const char* launch_resblock_chain(const ChainParams& p, hipStream_t s);
 double resblock_chain_flops(const ChainParams& p);
 double resblock_chain_bytes(const ChainParams& p);
+
+// ---- conv_bf16.hip: the convolutions of the vocoder in plain bf16 (precision "bf16", BASELINE config 5: the 48 kHz long-form stream).
+// out[b, t, n] = epilogue( sum_c sum_j bf16(f(in[b, t - pad + j dil, c])) * bf16(w[n, j, c]) ), fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16 in conv_gemm's order of terms (chunk-major, tap, k-step), so the result is BIT-IDENTICAL to conv_gemm /
+// conv_rows / the fused ResBlock kernels in mode 2 and the engine may pick per launch.  What differs is the shape of the work: the whole
+// [rows + halo] x Cin slab of a row tile sits in LDS as bf16 (converted ONCE while staging, or copied when the producer already wrote
+// bf16), so there is one workgroup barrier per tile instead of two per 32-channel chunk, and the weights stream from L2 through a ring of
+// D (chunk, tap) units per wavefront.  Made for what mode 2's shapes need: few rows with a long K (the 256-channel stage of a 542-frame
+// streaming window: 4 336 rows, K up to 2 816) and MFMA : fragment ratios that the L1's 64 B / clk can feed with a third of bf16x3's
+// MFMAs per fragment.
+struct BConvParams {
+  const void* in = nullptr;       // [B, T, Cin] channels-last, dense: fp32 (in_bf16 = 0) or bf16 (in_bf16 = 1)
+  int in_bf16 = 0;
+  float in_slope = 1.0f;          // fp32 input: leaky ReLU applied while staging (1 = identity); a bf16 input is taken as it is
+  const void* wimg = nullptr;     // launch_bf16_image's order
+  int KWe = 0;                    // taps the image holds per 32-column tile: KW, or 2 for a polyphase upsampler (tap_split != 0)
+  int tap_split = 0;              // polyphase upsampler (KW == 3, packer.polyphase_upsampler): columns < tap_split never use tap 2, columns
+                                  // >= tap_split never tap 0; the image holds the two live taps of each 32-column tile.  0: all taps
+  const float* bias = nullptr;    // [Cout] or null
+  float act_slope = 1.0f;         // v = max(v, v * act_slope) after the bias (1 = none, 0 = ReLU)
+  const float* res = nullptr;     // optional fp32 residual [B, T, Cout], added after the activation
+  int accumulate = 0;             // v = out_old + v   (needs out)
+  float out_div = 1.0f;           // then v / out_div  (needs accumulate)
+  float* out = nullptr;           // fp32 result [B, T, Cout] or null
+  void* out_b = nullptr;          // bf16 image of the result for the NEXT convolution, or null: bf16(max(v, v * outb_slope))
+  float outb_slope = 1.0f;
+  int B = 0, T = 0, Cin = 0, Cout = 0, KW = 1, dil = 1, pad = 0;
+  int rows_hint = 0;              // 0: tile shape by B x T; tuning aid otherwise (bench)
+};
+bool conv_bf16_supported(const BConvParams& p);
+const char* launch_conv_bf16(const BConvParams& p, hipStream_t s);
+// Up to BC_GROUP_MAX INDEPENDENT convolutions of the same geometry class (B, T, Cin, Cout, input type; kernel size, dilation, weights and
+// buffers may differ) in ONE launch: the parallel ResBlocks of a vocoder stage (reference V/generator.py:44-48) at small windows, where a
+// single convolution cannot fill the chip and three streams of short launches are bound by the host's enqueue rate.  Members are
+// dispatched in the order given (longest first is best).  Each member's result is what launch_conv_bf16 gives for it alone.
+constexpr int BC_GROUP_MAX = 4;
+const char* launch_conv_bf16_group(const BConvParams* p, int n, hipStream_t s);
+const char* conv_bf16_class(const BConvParams& p);
+// split-precision weight image [Cout][KW][ceil(Cin/32)][32 bf16 hi | 32 bf16 lo] (packer.pack_x3) -> the hi halves alone in the order
+// conv_bf16 streams them: [Cout/32][chunk][tap slot 0..KWe-1][k-step 0..1][lane 0..63][8 bf16] (2 KiB per (tile, chunk, tap), units of a
+// tile contiguous).  tap_split != 0 (KW == 3): tap slot s of tile t is tap s + (32 t >= tap_split ? 1 : 0), KWe = 2.
+size_t bf16_image_bytes(int Cout, int KW, int Cin, int tap_split);
+const char* launch_bf16_image(const float* x3, void* img, int Cout, int KW, int Cin, int tap_split, hipStream_t s);
 
 // split-precision weight image -> MFMA-fragment order (ConvParams::wfrag)
 const char* launch_x3_to_frag(const float* x3, float* frag, int Cout, int KW, int Cin, hipStream_t s);

@@ -88,14 +88,66 @@ __device__ __forceinline__ void bc_pipeline() {
 // round-to-nearest-even on the way (conv_gemm's mode-2 staging, value for value); bf16 input: copied.  SB 16-byte LDS pieces per thread
 // and batch -- all of a batch's loads are issued before the first is used, and SB is sized so that a slab is one or two batches (each
 // batch is a round trip to L2 / HBM with the CU otherwise idle: 6-piece batches took 8 600 cycles for a 178-row x 256-channel slab).
+// in_add / in_div (fp32 input only): further tensors summed into the input while staging -- x = (((in + a0) + a1) + a2) / div, the order and
+// operations of accum_div_kernel (small_kernels.hip), whose launch and whose pass over the tensors this replaces.
 template <bool IN_BF16, int SB>
 __device__ __forceinline__ void bc_stage(unsigned char* smem, const void* in_utt, const int T, const int Cin, const int NCH, const int RS,
-                                         const int t_first, const int srows, const float slope, const int tid) {
+                                         const int t_first, const int srows, const float slope, const int tid,
+                                         const float* a0 = nullptr, const float* a1 = nullptr, const float* a2 = nullptr, const float div = 1.0f) {
   const int ppr = NCH * 4;             // 16-byte pieces (8 channels) per LDS row
   const int npieces = srows * ppr;
   constexpr int esz = IN_BF16 ? 2 : 4;
   const __amdgpu_buffer_rsrc_t in_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(in_utt), 0, (int)((long long)T * Cin * esz), 0x00020000);
+  if constexpr (!IN_BF16) {
+    if (a0) {   // the joined form: four pieces per thread and batch, every input's loads issued before the first is used
+      constexpr int SJ = 4;
+      const int bytes = (int)((long long)T * Cin * 4);
+      const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a0), 0, bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a1 ? a1 : a0), 0, bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a2 ? a2 : a0), 0, bytes, 0x00020000);
+      for (int base = tid; base < npieces; base += 256 * SJ) {
+        float4 v[SJ][2], w0[SJ][2], w1[SJ][2], w2[SJ][2];
+        bool ok[SJ];
+        int dst[SJ];
+#pragma unroll
+        for (int i = 0; i < SJ; ++i) {
+          const int idx = base + i * 256;
+          const int row = idx / ppr, pc = idx - row * ppr;
+          const int t = t_first + row;
+          ok[i] = idx < npieces && t >= 0 && t < T && pc * 8 < Cin;
+          dst[i] = idx < npieces ? row * RS + pc * 16 : -1;
+          const int off = (min(max(t, 0), T - 1) * Cin + min(pc * 8, Cin - 8)) * 4;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            v[i][h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 16 * h, 0, 0));
+            w0[i][h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r0, off + 16 * h, 0, 0));
+            if (a1) w1[i][h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1, off + 16 * h, 0, 0));
+            if (a2) w2[i][h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r2, off + 16 * h, 0, 0));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < SJ; ++i) {
+          float4 x[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float4 a = v[i][h];
+            a.x += w0[i][h].x; a.y += w0[i][h].y; a.z += w0[i][h].z; a.w += w0[i][h].w;
+            if (a1) { a.x += w1[i][h].x; a.y += w1[i][h].y; a.z += w1[i][h].z; a.w += w1[i][h].w; }
+            if (a2) { a.x += w2[i][h].x; a.y += w2[i][h].y; a.z += w2[i][h].z; a.w += w2[i][h].w; }
+            if (div != 1.0f) { a.x = a.x / div; a.y = a.y / div; a.z = a.z / div; a.w = a.w / div; }
+            a.x = fmaxf(a.x, a.x * slope); a.y = fmaxf(a.y, a.y * slope); a.z = fmaxf(a.z, a.z * slope); a.w = fmaxf(a.w, a.w * slope);
+            x[h] = a;
+          }
+          uint4 o;
+          o.x = bc_pack(x[0].x, x[0].y); o.y = bc_pack(x[0].z, x[0].w); o.z = bc_pack(x[1].x, x[1].y); o.w = bc_pack(x[1].z, x[1].w);
+          if (!ok[i]) o = make_uint4(0, 0, 0, 0);
+          if (dst[i] >= 0) *reinterpret_cast<uint4*>(smem + dst[i]) = o;
+        }
+      }
+      return;
+    }
+  }
   for (int base = tid; base < npieces; base += 256 * SB) {
     float4 ra[SB], rb[SB];
     bool ok[SB];
@@ -280,7 +332,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const BConvGroup grp)
   // ---- slab: rows [t0 - pad, t0 - pad + srows) x all channels, as bf16
   constexpr int SB = (2 * NT * D >= 24) ? (IN_BF16 ? 12 : 8) : (IN_BF16 ? 16 : 12);   // the ring's registers are live while the slab is staged
   bc_stage<IN_BF16, SB>(smem, reinterpret_cast<const char*>(p.in) + (long long)b * p.T * p.Cin * (IN_BF16 ? 2 : 4), p.T, p.Cin, NCH, RS,
-                                       t0 - p.pad, srows, p.in_slope, tid);
+                                       t0 - p.pad, srows, p.in_slope, tid,
+                                       p.in_add[0] ? p.in_add[0] + (long long)b * p.T * p.Cin : nullptr, p.in_add[1] ? p.in_add[1] + (long long)b * p.T * p.Cin : nullptr,
+                                       p.in_add[2] ? p.in_add[2] + (long long)b * p.T * p.Cin : nullptr, p.in_div);
   BC_STAMP(st2);
   __syncthreads();   // the one barrier of the tile: slab visible
   BC_STAMP(st3);
@@ -542,6 +596,249 @@ __global__ __launch_bounds__(256, 2) void pair_bf16_kernel(const BPairGroup grp)
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// rb_bf16: a whole ResBlock1 in one launch (kernels.h: RbParams).  A workgroup owns R = 512 consecutive positions (a tile) of one
+// utterance and ALL C channels: 4 wavefronts of 128 positions x 32 channels at C = 32, 8 wavefronts (4 x 2) at C = 64.  Every pair is
+// computed on all R positions; positions whose receptive field left the tile come out wrong and are never stored (pair m consumes
+// hk (d_m + 1) positions per edge, hk = (KW - 1) / 2: H = 12 / 36 / 60 for the kernel sizes 3 / 7 / 11 at dilations 1, 3, 5).
+//   * residual stream x_m: registers, accumulator layout (lane = position, register quad = four consecutive channels);
+//   * LDS: X = bf16(lrelu(x_m)) with gx = hk d_max guard rows of zeros at either end, I = bf16(lrelu(c1 + b1)) with hk guard rows; rows
+//     outside [0, T) are zero in both (the convolutions' zero padding);
+//   * two workgroup barriers per pair; the weights of the next convolution's first D units are requested before each epilogue.
+struct BRbGroup {
+  int n;
+  int wg_end[BC_GROUP_MAX];
+  int rtiles[BC_GROUP_MAX];
+  RbParams p[BC_GROUP_MAX];
+};
+
+template <int MT, int WGM, int WGN, int D, bool ACCUM>
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void rb_bf16_kernel(const BRbGroup grp) {
+  constexpr int NT = 1;
+  constexpr int NWAVE = WGM * WGN, NTHR = 64 * NWAVE;
+  constexpr int C = 32 * WGN;
+  constexpr int NCH = WGN;
+  constexpr int R = 32 * MT * WGM;
+  constexpr int RS = NCH * 64 + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  int member = 0;
+  for (int k = 0; k + 1 < grp.n; ++k) member += (int)blockIdx.x >= grp.wg_end[k] ? 1 : 0;
+  const RbParams& p = grp.p[member];
+  const int bid = (int)blockIdx.x - (member ? grp.wg_end[member - 1] : 0);
+  const int rtiles = grp.rtiles[member];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = bid / rtiles, tile = bid - b * rtiles;
+  const int KW = p.KW, hk = (KW - 1) / 2, NP = p.n_pairs;
+  int H = 0, gx = 0;
+  for (int m = 0; m < NP; ++m) {
+    H += hk * (p.dil[m] + 1);
+    gx = max(gx, hk * p.dil[m]);
+  }
+  const int RO = R - 2 * H;             // valid output positions per tile
+  const int xrows = R + 2 * gx;
+  unsigned char* Xs = smem;
+  unsigned char* Is = smem + xrows * RS;
+  const int origin = tile * RO - H;     // global position of tile row 0
+  const int NU = NCH * KW;
+  const int nt0 = wn;
+  const float* x_b = p.x + (long long)b * p.x_bs;
+  float* out_b = p.out + (long long)b * p.out_bs;
+
+  unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, sc1 = 0, se1 = 0, sc2 = 0, se2 = 0;
+  BC_STAMP(d0);
+  uint4 wr[D][2][NT];
+  bf16x8 xb[2][2][MT];
+  f32x16 acc[MT][NT], xres[MT];
+  E2ETTS_BC_LAMBDAS
+  // the first convolution's first D units
+  {
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[0][0]), 0, NCH * NU * 2048, 0x00020000);
+    E2ETTS_BC_RING_FILL(w_rsrc, nt0, NU)
+  }
+  // ---- zero the guard rows of both images (never written again)
+  for (int i = tid; i < 2 * gx * (RS / 16); i += NTHR) {
+    const int r = i / (RS / 16), c16 = i - r * (RS / 16);
+    const int row = r < gx ? r : R + r;   // rows [0, gx) and [R + gx, R + 2 gx)
+    *reinterpret_cast<uint4*>(Xs + row * RS + c16 * 16) = make_uint4(0, 0, 0, 0);
+  }
+  for (int i = tid; i < 2 * hk * (RS / 16); i += NTHR) {
+    const int r = i / (RS / 16), c16 = i - r * (RS / 16);
+    const int row = r < hk ? r : R + r;
+    *reinterpret_cast<uint4*>(Is + row * RS + c16 * 16) = make_uint4(0, 0, 0, 0);
+  }
+  // ---- x_0 into registers: lane (li, lh) = position li of the block, register 4 q + i = channel 8 q + 4 lh + i of the wavefront's 32.
+  // Global memory is read in whole row segments (8 lanes x 16 B = the wavefront's 128 B of a row, 8 rows per instruction) into a
+  // wave-private LDS patch and picked up from there in accumulator layout: read straight in that layout -- 32 bytes per row and
+  // instruction -- the 16 loads of a 512-position tile and the 16 stores at the end took 17 000 + 30 000 of the tile's 65 000 cycles.
+  // The patches lie in I's interior (written by nobody before pair 0's conv1 is done).
+  constexpr int ELD = 36;                 // patch row stride (floats): a 16-lane group of b128 accesses covers all 64 banks once
+  constexpr int LPR = 8, RPP = 8, PASSES = 4;
+  const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+  {
+    float* patch = reinterpret_cast<float*>(Is + hk * RS) + wave * (32 * ELD);
+    float4 rowv[MT][PASSES];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int g = origin + wm * (32 * MT) + m * 32 + ps * RPP + prow;
+        const float4 v = *reinterpret_cast<const float4*>(x_b + (long long)min(max(g, 0), p.T - 1) * C + wn * 32 + pc4);
+        rowv[m][ps] = (g >= 0 && g < p.T) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) *reinterpret_cast<float4*>(patch + (ps * RPP + prow) * ELD + pc4) = rowv[m][ps];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(patch + li * ELD + 8 * q + 4 * lh);
+        xres[m][4 * q + 0] = v.x; xres[m][4 * q + 1] = v.y; xres[m][4 * q + 2] = v.z; xres[m][4 * q + 3] = v.w;
+      }
+    }
+  }
+  // an accumulator-layout tile -> operand image: (+ bias), lrelu, zero outside [0, T), round to bf16; four consecutive channels of one
+  // position per register quad = 8 bytes of that position's row
+  auto write_image = [&](const f32x16 (&src)[MT], unsigned char* img, const int guard, const float* bias /* [C] or null */) __attribute__((always_inline)) {
+    float4 bq[4];
+    if (bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + wn * 32 + 8 * q + 4 * lh);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row = wm * (32 * MT) + m * 32 + li;
+      const int g = origin + row;
+      const bool ok = g >= 0 && g < p.T;
+      unsigned char* dst = img + (row + guard) * RS + wn * 64 + lh * 8;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4] = {src[m][4 * q], src[m][4 * q + 1], src[m][4 * q + 2], src[m][4 * q + 3]};
+        if (bias) { v[0] += bq[q].x; v[1] += bq[q].y; v[2] += bq[q].z; v[3] += bq[q].w; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = fmaxf(v[i], v[i] * p.slope);
+          v[i] = ok ? v[i] : 0.f;
+        }
+        uint2 h;
+        h.x = bc_pack(v[0], v[1]);
+        h.y = bc_pack(v[2], v[3]);
+        *reinterpret_cast<uint2*>(dst + q * 16) = h;
+      }
+    }
+  };
+  write_image(xres, Xs, gx, nullptr);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
+
+  BC_STAMP(d1);
+  for (int pm = 0; pm < NP; ++pm) {
+    const int d = p.dil[pm];
+    __syncthreads();  // X = lrelu(x_pm) visible (and every wavefront is done with I of the previous pair)
+    BC_STAMP(d2);
+    // conv1: position r reads X rows r + gx + (j - hk) d
+    {
+      const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[pm][0]), 0, NCH * NU * 2048, 0x00020000);
+      const unsigned char* a_lane = Xs + (wm * (32 * MT) + li + gx - hk * d) * RS + lh * 16;
+      const int tap_step = d * RS;
+      E2ETTS_BC_KLOOP(w_rsrc, nt0, NU, a_lane, KW, tap_step)
+    }
+    BC_STAMP(d3);
+    sc1 += d3 - d2;
+    const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[pm][1]), 0, NCH * NU * 2048, 0x00020000);
+    E2ETTS_BC_RING_FILL(w2_rsrc, nt0, NU)
+    {
+      f32x16 t[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) t[m] = acc[m][0];
+      write_image(t, Is, hk, p.b1[pm]);   // I = lrelu(c1 + b1), zero outside [0, T)
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
+    __syncthreads();  // I visible; every wavefront is done reading X
+    BC_STAMP(d4);
+    se1 += d4 - d3;
+    // conv2: position r reads I rows r + hk + (j - hk) = r + j
+    {
+      const unsigned char* a_lane = Is + (wm * (32 * MT) + li) * RS + lh * 16;
+      const int tap_step = RS;
+      E2ETTS_BC_KLOOP(w2_rsrc, nt0, NU, a_lane, KW, tap_step)
+    }
+    BC_STAMP(d5);
+    sc2 += d5 - d4;
+    if (pm + 1 < NP) {
+      const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[pm + 1][0]), 0, NCH * NU * 2048, 0x00020000);
+      E2ETTS_BC_RING_FILL(w_rsrc, nt0, NU)
+    }
+    // x_{pm+1} = (c2 + b2) + x_pm, in registers
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.b2[pm] + wn * 32 + 8 * q + 4 * lh);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        xres[m][4 * q + 0] = (acc[m][0][4 * q + 0] + bv.x) + xres[m][4 * q + 0];
+        xres[m][4 * q + 1] = (acc[m][0][4 * q + 1] + bv.y) + xres[m][4 * q + 1];
+        xres[m][4 * q + 2] = (acc[m][0][4 * q + 2] + bv.z) + xres[m][4 * q + 2];
+        xres[m][4 * q + 3] = (acc[m][0][4 * q + 3] + bv.w) + xres[m][4 * q + 3];
+        acc[m][0][4 * q + 0] = 0.f; acc[m][0][4 * q + 1] = 0.f; acc[m][0][4 * q + 2] = 0.f; acc[m][0][4 * q + 3] = 0.f;
+      }
+    }
+    if (pm + 1 < NP) write_image(xres, Xs, gx, nullptr);  // X is dead since the barrier above
+#ifdef E2ETTS_BC_DIAG
+    { unsigned long long dz; BC_STAMP(dz); se2 += dz - d5; }
+#endif
+  }
+  BC_STAMP(d2);
+
+  // ---- out = x_n (+ out_old, / div) on the positions this tile owns: tile rows [H, R - H), global rows < T.  Through wave-private patches
+  // again (over X, dead since the last conv1), so that the stores are whole row segments.
+  const int g_end = min((tile + 1) * RO, p.T);
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  {
+    float* patch = reinterpret_cast<float*>(Xs) + wave * (32 * ELD);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4_t ov[PASSES];
+      if (ACCUM && p.accumulate) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int g = origin + wm * (32 * MT) + m * 32 + ps * RPP + prow;
+          ov[ps] = *reinterpret_cast<const f32x4_t*>(out_b + (long long)min(max(g, 0), p.T - 1) * C + wn * 32 + pc4);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(patch + li * ELD + 8 * q + 4 * lh) = make_float4(xres[m][4 * q], xres[m][4 * q + 1], xres[m][4 * q + 2], xres[m][4 * q + 3]);
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = wm * (32 * MT) + m * 32 + ps * RPP + prow;
+        const int g = origin + row;
+        const float4 pv = *reinterpret_cast<const float4*>(patch + (ps * RPP + prow) * ELD + pc4);
+        f32x4_t v = {pv.x, pv.y, pv.z, pv.w};
+        if (ACCUM && p.accumulate) {
+          v += ov[ps];
+          if (p.out_div != 1.0f) v = v / p.out_div;
+        }
+        if (row >= H && row < R - H && g < g_end) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(out_b + (long long)g * C + wn * 32 + pc4));
+      }
+    }
+  }
+#ifdef E2ETTS_BC_DIAG
+  BC_STAMP(d3);
+  if (tid == 0 && member == 0) {
+    atomicAdd(&g_bc_diag[0], d1 - d0); atomicAdd(&g_bc_diag[1], sc1); atomicAdd(&g_bc_diag[2], se1); atomicAdd(&g_bc_diag[3], sc2);
+    atomicAdd(&g_bc_diag[4], se2); atomicAdd(&g_bc_diag[5], d3 - d2); atomicAdd(&g_bc_diag[6], d3 - d0); atomicAdd(&g_bc_diag[7], 1ull);
+  }
+#endif
+}
+
 // hi halves of the split-precision image in conv_bf16's order; one thread moves one lane's 16 bytes
 __global__ void bf16_image_kernel(const uint4* __restrict__ x3, uint4* __restrict__ img, int Cout, int KW, int KWe, int nchunk, int tap_split,
                                   long long groups) {
@@ -653,6 +950,9 @@ static const char* bc_check(const BConvParams& p) {
   if (!p.in || !p.wimg || (!p.out && !p.out_b)) return "conv_bf16: null pointer";
   if (!conv_bf16_supported(p)) return "conv_bf16: unsupported shape";
   if (p.accumulate && !p.out) return "conv_bf16: accumulate needs the fp32 output";
+  if (p.in_add[0] && p.in_bf16) return "conv_bf16: in_add needs an fp32 input";
+  if ((p.in_add[1] && !p.in_add[0]) || (p.in_add[2] && !p.in_add[1])) return "conv_bf16: in_add must be filled from the front";
+  if (((uintptr_t)p.in_add[0] | (uintptr_t)p.in_add[1] | (uintptr_t)p.in_add[2]) & 15) return "conv_bf16: pointers must be 16-byte aligned";
   if (p.out_div != 1.0f && !p.accumulate) return "conv_bf16: out_div needs accumulate";
   if (((uintptr_t)p.in | (uintptr_t)p.wimg | (uintptr_t)p.out | (uintptr_t)p.out_b | (uintptr_t)p.res | (uintptr_t)p.bias) & 15)
     return "conv_bf16: pointers must be 16-byte aligned";
@@ -768,6 +1068,90 @@ const char* launch_pair_bf16_group(const PairParams* ps, int n, hipStream_t s) {
 }
 
 const char* launch_pair_bf16(const PairParams& p, hipStream_t s) { return launch_pair_bf16_group(&p, 1, s); }
+
+namespace {
+
+void rb_geometry(const RbParams& p, int& H, int& gx) {
+  const int hk = (p.KW - 1) / 2;
+  H = 0; gx = 0;
+  for (int m = 0; m < p.n_pairs; ++m) {
+    H += hk * (p.dil[m] + 1);
+    gx = std::max(gx, hk * p.dil[m]);
+  }
+}
+
+template <int MT, int WGM, int WGN, int D>
+const char* rb_launch(const RbParams* ps, int n, hipStream_t s) {
+  constexpr int R = 32 * MT * WGM, RS = WGN * 64 + 16;
+  BRbGroup g;
+  g.n = n;
+  size_t lds = 0;
+  long long nwg = 0;
+  bool any_acc = false;
+  for (int k = 0; k < n; ++k) {
+    int H, gx;
+    rb_geometry(ps[k], H, gx);
+    const int RO = R - 2 * H, hk = (ps[k].KW - 1) / 2;
+    lds = std::max(lds, (size_t)((R + 2 * gx) + (R + 2 * hk)) * RS + 64);
+    g.rtiles[k] = (ps[k].T + RO - 1) / RO;
+    nwg += (long long)g.rtiles[k] * ps[k].B;
+    g.wg_end[k] = (int)nwg;
+    g.p[k] = ps[k];
+    any_acc = any_acc || ps[k].accumulate;
+  }
+  for (int k = n; k < BC_GROUP_MAX; ++k) { g.wg_end[k] = (int)nwg; g.rtiles[k] = 1; }
+  if (lds > 160 * 1024) return "rb_bf16: LDS images exceed the CU's 160 KiB";
+  if (nwg >= (1LL << 31)) return "rb_bf16: grid too large";
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_bf16_kernel<MT, WGM, WGN, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_bf16_kernel<MT, WGM, WGN, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (any_acc) hipLaunchKernelGGL((rb_bf16_kernel<MT, WGM, WGN, D, true>), dim3((unsigned)nwg), dim3(64 * WGM * WGN), lds, s, g);
+  else hipLaunchKernelGGL((rb_bf16_kernel<MT, WGM, WGN, D, false>), dim3((unsigned)nwg), dim3(64 * WGM * WGN), lds, s, g);
+  return hipGetLastError() == hipSuccess ? nullptr : "rb_bf16: launch failed";
+}
+
+}  // namespace
+
+bool rb_bf16_supported(const RbParams& p) {
+  static const bool on = !(getenv("E2ETTS_BRB") && atoi(getenv("E2ETTS_BRB")) == 0);   // tuning aid: 0 keeps the pair launches
+  if (!on || !(p.C == 32 || p.C == 64) || !(p.KW & 1) || p.KW < 3 || p.KW > 15 || p.n_pairs < 1 || p.n_pairs > RB_MAX_PAIRS) return false;
+  int H, gx;
+  rb_geometry(p, H, gx);
+  for (int m = 0; m < p.n_pairs; ++m)
+    if (p.dil[m] < 1 || !p.bimg[m][0] || !p.bimg[m][1] || !p.b1[m] || !p.b2[m]) return false;
+  if (512 - 2 * H < 256) return false;   // more than half a tile recomputed
+  const size_t lds = (size_t)((512 + 2 * gx) + (512 + (p.KW - 1))) * ((p.C / 32) * 64 + 16) + 64;
+  if (lds > 160 * 1024) return false;
+  if (p.x_bs != (long long)p.T * p.C || p.out_bs != (long long)p.T * p.C) return false;
+  return (long long)p.T * p.C * 4 < (1LL << 31);
+}
+
+double rb_bf16_flops(const RbParams& p) { return p.n_pairs * 2.0 * 2.0 * p.B * (double)p.T * p.C * p.KW * p.C; }
+double rb_bf16_bytes(const RbParams& p) { return 4.0 * ((double)p.B * p.T * p.C * (2.0 + (p.accumulate ? 1 : 0)) + p.n_pairs * 2.0 * p.C * p.KW * p.C / 2.0); }
+
+const char* launch_rb_bf16_group(const RbParams* ps, int n, hipStream_t s) {
+  if (!ps || n < 1 || n > BC_GROUP_MAX) return "rb_bf16: a group has 1 .. BC_GROUP_MAX members";
+  for (int k = 0; k < n; ++k) {
+    const RbParams& p = ps[k];
+    if (!p.x || !p.out) return "rb_bf16: null pointer";
+    if (p.B <= 0 || p.T <= 0) return "rb_bf16: bad dims";
+    if (!rb_bf16_supported(p)) return "rb_bf16: unsupported launch";
+    if (p.slope < 0.f || p.slope > 1.f) return "rb_bf16: slope must lie in [0, 1]";
+    if (p.out_div != 1.0f && !p.accumulate) return "rb_bf16: out_div needs accumulate";
+    if (((uintptr_t)p.x | (uintptr_t)p.out) & 15) return "rb_bf16: pointers must be 16-byte aligned";
+    for (int m = 0; m < p.n_pairs; ++m)
+      if (((uintptr_t)p.bimg[m][0] | (uintptr_t)p.bimg[m][1] | (uintptr_t)p.b1[m] | (uintptr_t)p.b2[m]) & 15) return "rb_bf16: weights and biases must be 16-byte aligned";
+    if (p.x == p.out) return "rb_bf16: in-place is not possible (tiles read their neighbours' rows)";
+    if (p.B != ps[0].B || p.T != ps[0].T || p.C != ps[0].C) return "rb_bf16: the members of a group share B, T and C";
+  }
+  // 32 channels: 8 wavefronts of 64 positions each (two per SIMD: one covers the other's image writes and barriers) or 4 of 128
+  static const int w32 = getenv("E2ETTS_BRB_W32") ? atoi(getenv("E2ETTS_BRB_W32")) : 8;   // tuning aid
+  if (ps[0].C == 32) return w32 == 4 ? rb_launch<4, 4, 1, 4>(ps, n, s) : rb_launch<2, 8, 1, 8>(ps, n, s);
+  return rb_launch<4, 4, 2, 4>(ps, n, s);
+}
 
 size_t bf16_image_bytes(int Cout, int KW, int Cin, int tap_split) {
   return (size_t)((Cout + 31) / 32) * ((Cin + 31) / 32) * (tap_split > 0 ? 2 : KW) * 2048;

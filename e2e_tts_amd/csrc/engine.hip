@@ -278,6 +278,8 @@ bool bconv_params(const ConvParams& p, BConvParams& q) {
   if (p.bimg_tap_split != p.zero_tap_split) return false;
   q = BConvParams();
   q.in = p.in; q.in_bf16 = p.in_bf16; q.in_slope = p.in_slope; q.wimg = p.bimg; q.tap_split = p.bimg_tap_split;
+  for (int k = 0; k < 3; ++k) q.in_add[k] = p.in_add[k];
+  q.in_div = p.in_div;
   q.KWe = p.bimg_tap_split > 0 ? 2 : p.KW;
   q.bias = p.bias; q.act_slope = p.act == ACT_LRELU ? p.act_slope : (p.act == ACT_RELU ? 0.f : 1.f);
   q.res = p.res; q.accumulate = p.accumulate; q.out_div = p.out_div; q.out = p.out; q.out_b = p.out_b; q.outb_slope = p.outb_slope;
@@ -313,7 +315,7 @@ int conv(e2etts_engine* e, ConvParams p, double alg_scale = 1.0, bool ksplit = f
       KCHK(e, launch_conv_bf16(q, e->stream));
       return E2ETTS_OK;
     }
-    if (p.in_bf16 || p.out_b) return e->fail(E2ETTS_EINVAL, "bf16 hand-over asked of a launch conv_bf16 does not serve");
+    if (p.in_bf16 || p.out_b || p.in_add[0]) return e->fail(E2ETTS_EINVAL, "bf16 hand-over / joined input asked of a launch conv_bf16 does not serve");
   }
   static const bool ksplit_on = !(getenv("E2ETTS_KSPLIT") && atoi(getenv("E2ETTS_KSPLIT")) == 0);
   // ... and only where the chain is long (K = KW x Cin >= 768: the FFN convolutions, the predictors): a q | k | v or fc projection
@@ -1152,6 +1154,21 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       if (it != e->bimg_of.end()) { q.bimg = it->second.first; q.bimg_tap_split = it->second.second; }
     }
   };
+  // plain bf16: a whole ResBlock1 of stage `stage`, kernel index j, as ONE launch (conv_bf16.hip: rb_bf16) where that applies
+  auto rb_params = [&](int stage, int j, int co, long long n, const float* x, float* out, RbParams& q) -> bool {
+    if (e->voc_precision != E2ETTS_PRECISION_BF16 || c.voc_resblock != 1 || c.voc_n_dil > RB_MAX_PAIRS) return false;
+    const int idx = stage * c.voc_n_kernels + j;
+    q = RbParams();
+    q.x = x; q.out = out; q.n_pairs = c.voc_n_dil; q.B = B; q.T = (int)n; q.C = co; q.KW = c.voc_rb_kernel[j];
+    q.x_bs = q.out_bs = n * co; q.slope = 0.1f;
+    for (int m = 0; m < c.voc_n_dil; ++m) {
+      auto i1 = e->bimg_of.find(e->rb_c1[idx][m].wx3), i2 = e->bimg_of.find(e->rb_c2[idx][m].wx3);
+      if (i1 == e->bimg_of.end() || i2 == e->bimg_of.end()) return false;
+      q.bimg[m][0] = i1->second.first; q.bimg[m][1] = i2->second.first;
+      q.b1[m] = e->rb_c1[idx][m].b; q.b2[m] = e->rb_c2[idx][m].b; q.dil[m] = c.voc_rb_dil[j][m];
+    }
+    return rb_bf16_supported(q);
+  };
   // Ragged mode: the layers of stage i compute rows < mel_len * rate_i + halo_i only (host_logic.h: vocoder_stage_halo_rows -- the
   // reach of what is still to come, in that stage's rows: 12 frames after conv_pre, 76 / 109 / 94 / 63 rows in the four stages of
   // HiFi-GAN V1).  What lies beyond is stale but finite and out of the reach of every valid sample.
@@ -1231,15 +1248,27 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   RET(conv(e, p));
   long long n = T;
   ch = c.voc_init_ch;
+  // stage i's upsampler on n_in rows of ch_in channels (input S)
+  auto make_up = [&](int i, long long n_in, long long ch_in, ConvParams& q) {
+    const int s = c.voc_up_rate[i];
+    const int co = (int)ch_in / 2;
+    q = ConvParams();
+    q.B = B; q.T = (int)n_in; q.act_rows = act_stage[i]; q.act_rows_host = act_stage_h[i]; q.act_frac = vfs[i]; q.in = S; setw(q, e->voc_up[i]); q.out = XU; q.Cin = (int)ch_in; q.Cout = s * co;
+    q.KW = 3; q.pad = 1; q.in_slope = 0.1f;
+    q.zero_tap_split = s * co / 2;  // phases < s/2 never use tap 2, the others never tap 0 (packer.polyphase_upsampler)
+  };
+  // a join that the NEXT layer performs while staging its input (grouped stages, below): S = (((S + pend_add[0]) + ...) / pend_div
+  const float* pend_add[3] = {nullptr, nullptr, nullptr};
+  float pend_div = 1.0f;
   for (int i = 0; i < c.voc_stages; ++i) {
     const int s = c.voc_up_rate[i];
     const int co = (int)ch / 2;
     // leaky_relu(0.1) -> ConvTranspose1d(k = 2s, stride s, pad s/2)  (V/generator.py:40-41) as a 3-tap convolution
     // with s * co output channels: row q of the [n, s*co] result IS rows q*s .. q*s+s-1 of the [n*s, co] signal.
-    p = ConvParams();
-    p.B = B; p.T = (int)n; p.act_rows = act_stage[i]; p.act_rows_host = act_stage_h[i]; p.act_frac = vfs[i]; p.in = S; setw(p, e->voc_up[i]); p.out = XU; p.Cin = (int)ch; p.Cout = s * co;
-    p.KW = 3; p.pad = 1; p.in_slope = 0.1f;
-    p.zero_tap_split = s * co / 2;  // phases < s/2 never use tap 2, the others never tap 0 (packer.polyphase_upsampler)
+    make_up(i, n, ch, p);
+    for (int k = 0; k < 3; ++k) p.in_add[k] = pend_add[k];   // the previous stage's join, folded into this layer's input (see below)
+    p.in_div = pend_div;
+    pend_add[0] = pend_add[1] = pend_add[2] = nullptr; pend_div = 1.0f;
     RET(conv(e, p, 2.0 / 3.0));
     n *= s;
     ch = co;
@@ -1256,8 +1285,26 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       }
       std::sort(order, order + nk, [&](int a, int b2) { return c.voc_rb_kernel[a] > c.voc_rb_kernel[b2]; });
       const bool as_pairs = co <= 128;
+      // 32 / 64 channels: the WHOLE ResBlock of every kernel size in one launch (these stages' tensors, 35 MB per 542-frame window at 48 kHz,
+      // stream through the Infinity Cache: pair by pair each is read twice and written once per pair)
+      {
+        RbParams rq[E2ETTS_MAX_RB_KERNELS];
+        bool rb_ok = e->fuse_pairs >= 2;
+        double fl = 0, by = 0;
+        for (int t = 0; t < nk && rb_ok; ++t) {
+          rb_ok = rb_params(i, order[t], co, n, XU, Sj[order[t]], rq[t]);
+          if (rb_ok) { fl += rb_bf16_flops(rq[t]); by += rb_bf16_bytes(rq[t]); }
+        }
+        if (rb_ok) {
+          char nm[48];
+          snprintf(nm, sizeof nm, "rb_bf16_group_%d", co);
+          ProfScope ps(e, nm, fl, by);
+          KCHK(e, launch_rb_bf16_group(rq, nk, e->stream));
+          grouped_stage = true;
+        }
+      }
       // every member of every launch must be servable: decided before anything is launched
-      bool ok = true;
+      bool ok = !grouped_stage;
       for (int j = 0; j < nk && ok; ++j)
         for (int m = 0; m < c.voc_n_dil && ok; ++m) {
           const int idx = i * nk + j;
@@ -1365,6 +1412,24 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       // batches: 52 tiles at B = 1, T = 768) the two-launch form on 64 x 64 tiles fills the chip better (B = 1: 5.99 vs 6.45 ms per
       // utterance).  Both forms give the same bits, so the choice is invisible in the output.
       if (fused && co == 256 && (long long)B * (n / 128) < 256) fused = false;
+      // plain bf16, padded batch: the whole ResBlock in one launch on conv_bf16.hip's machinery, any kernel size at 32 / 64 channels
+      bool whole_rb = false;
+      // (at large grids the pair / chain kernels, two or three workgroups per CU, are ahead of this one-workgroup-per-CU kernel:
+      // measured 7.9 against 8.4 ms for the 60 s utterance in one call; E2ETTS_BRB_ALWAYS=1 takes it there too -- same bits)
+      static const bool rb_always = getenv("E2ETTS_BRB_ALWAYS") && atoi(getenv("E2ETTS_BRB_ALWAYS")) != 0;
+      if (rb_always && fused && e->fuse_pairs >= 2 && !act_stage[i + 1]) {
+        RbParams rq;
+        if (rb_params(i, j, co, n, XU, S, rq)) {
+          rq.accumulate = !conc && j > 0;
+          if (j == c.voc_n_kernels - 1 && rq.accumulate) rq.out_div = (float)c.voc_n_kernels;
+          char nm[48];
+          snprintf(nm, sizeof nm, "rb_bf16_%d", co);
+          ProfScope ps(e, nm, rb_bf16_flops(rq), rb_bf16_bytes(rq));
+          KCHK(e, launch_rb_bf16(rq, e->stream));
+          whole_rb = true;
+          fused = false;   // nothing left for the pair / chain / two-launch forms below
+        }
+      }
       // the whole ResBlock in one launch (resblock_chain.hip) where it exists: kernel size 3 at 32 / 64 channels
       const bool chained = fused && !f32 && e->fuse_pairs >= 2 && resblock_chain_supported(co, k, c.voc_rb_dil[j], c.voc_n_dil);
       if (chained) {
@@ -1428,7 +1493,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         RET(conv(e, p));
         cur = p.out;
       }
-      for (int m = 0; m < c.voc_n_dil && !fused && c.voc_resblock == 1; ++m) {
+      for (int m = 0; m < c.voc_n_dil && !fused && !whole_rb && c.voc_resblock == 1; ++m) {
         const int d = c.voc_rb_dil[j][m];
         // xt = c1(lrelu(x)); the lrelu that feeds c2 is applied here, in c1's epilogue (V/layers.py:35-38)
         p = ConvParams();
@@ -1466,7 +1531,30 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       }
       if (aside) HIPCHK(e, hipEventRecord(e->ev_join[j - 1], e->stream));
     }
-    if (conc) {  // join: S = ((S_0 + S_1) + S_2 ...) / num_kernels, the accumulating epilogues' order
+    // A grouped stage leaves its join to the layer that reads the sum -- the next upsampler (conv_bf16.hip stages (S_0 + S_1 + S_2) / 3 from
+    // the three tensors) or conv_post -- where that layer can take it: accum_div's additions and division in its order (same bits), without
+    // its launch and its pass over four tensors (142 MB at the 32- and 64-channel stages of a 542-frame window at 48 kHz).
+    bool deferred = false;
+    static const bool defer_env = !(getenv("E2ETTS_VOC_DEFER_JOIN") && atoi(getenv("E2ETTS_VOC_DEFER_JOIN")) == 0);   // tuning aid
+    if (conc && grouped_stage && defer_env && nk <= 4) {
+      bool can = false;
+      if (i + 1 < c.voc_stages) {
+        ConvParams q;
+        make_up(i + 1, n, ch, q);
+        q.in_ld = q.Cin; q.out_ld = q.Cout; q.in_bs = (long long)q.T * q.Cin; q.out_bs = (long long)q.T * q.Cout;
+        q.in_add[0] = ptr<float>(e->vside[0][0]);
+        BConvParams bq;
+        can = bconv_params(q, bq);
+      } else {
+        can = !istft;
+      }
+      if (can) {
+        for (int j = 1; j < nk; ++j) pend_add[j - 1] = ptr<float>(e->vside[j - 1][0]);
+        pend_div = (float)nk;
+        deferred = true;
+      }
+    }
+    if (conc && !deferred) {  // join: S = ((S_0 + S_1) + S_2 ...) / num_kernels, the accumulating epilogues' order
       for (int j = 1; j < nk && !grouped_stage; ++j) HIPCHK(e, hipStreamWaitEvent(main_stream, e->ev_join[j - 1], 0));
       for (int j = 1; j < nk; j += 2) {  // two side sums per pass: (S + S_j) + S_j+1, the same additions in the same order
         const bool two = j + 1 < nk;
@@ -1502,7 +1590,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   } else {
     ProfScope ps(e, "conv_post", 2.0 * B * (double)n * 7 * ch, (double)B * n * (ch * 4.0 + 6.0));
     KCHK(e, launch_conv_post(S, e->voc_post.w, e->voc_post.b, ptr<float>(e->wav), ptr<int16_t>(e->pcm), B, n, (int)ch, 7, e->stream,
-                             act_stage[c.voc_stages], act_stage_h[c.voc_stages]));
+                             act_stage[c.voc_stages], act_stage_h[c.voc_stages], pend_add[0] ? pend_add : nullptr, pend_div));
   }
   (void)want_wav; (void)want_pcm;
   e->voc_B = B; e->voc_T = T;

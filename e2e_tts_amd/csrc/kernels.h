@@ -68,6 +68,8 @@ struct ConvParams {
   const void* bimg = nullptr;
   int bimg_tap_split = 0;
   int in_bf16 = 0;        // `in` points at bf16 [B, T, Cin]
+  const float* in_add[3] = {nullptr, nullptr, nullptr};   // see BConvParams::in_add / in_div
+  float in_div = 1.0f;
   void* out_b = nullptr;  // bf16(max(v, v * outb_slope)) [B, T, Cout]; `out` may then be null
   float outb_slope = 1.0f;
 };
@@ -164,6 +166,33 @@ bool resblock_pair_supported(int C, int KW, int dil);
 bool pair_bf16_supported(const PairParams& p);
 const char* launch_pair_bf16(const PairParams& p, hipStream_t s);
 const char* launch_pair_bf16_group(const PairParams* p, int n, hipStream_t s);   // as launch_conv_bf16_group: same B, T, C; KW / dil / buffers per member
+
+// A WHOLE ResBlock1 (reference V/layers.py:33-40: n_pairs x [lrelu -> conv k, dilation d_m -> lrelu -> conv k -> + x]) in one launch, plain
+// bf16, any odd kernel size, 32 or 64 channels: resblock_chain.hip's scheme (residual stream in registers, two operand images in LDS, every
+// pair computed on all R = 512 positions of a tile and the sum_m (k - 1) / 2 (d_m + 1) positions per edge that saw a neighbour's rows
+// discarded) on conv_bf16.hip's machinery.  HBM / Infinity-Cache traffic per ResBlock: x in, out out (+ out in) -- against three passes per
+// PAIR as pair launches, which is what bounds the 32- and 64-channel stages (tensors of 35 MB per 542-frame window at 48 kHz, far beyond
+// an XCD's 4 MB of L2).  Same arithmetic in the same order as launch_pair_bf16 / launch_resblock_pair in mode 2: same bits.
+constexpr int RB_MAX_PAIRS = 4;
+struct RbParams {
+  const float* x = nullptr;      // [B, T, C] channels-last
+  float* out = nullptr;          // [B, T, C], must not alias x
+  const void* bimg[RB_MAX_PAIRS][2] = {};   // conv1 / conv2 weights of pair m in launch_bf16_image's order
+  const float* b1[RB_MAX_PAIRS] = {};
+  const float* b2[RB_MAX_PAIRS] = {};
+  int dil[RB_MAX_PAIRS] = {1, 1, 1, 1};
+  int n_pairs = 3;
+  int B = 0, T = 0, C = 0, KW = 3;
+  long long x_bs = 0, out_bs = 0;
+  float slope = 0.1f;
+  int accumulate = 0;            // out = out_old + result
+  float out_div = 1.0f;          // then / out_div (needs accumulate)
+};
+bool rb_bf16_supported(const RbParams& p);
+const char* launch_rb_bf16_group(const RbParams* p, int n, hipStream_t s);   // members share B, T, C, n_pairs; KW / dilations / buffers per member
+inline const char* launch_rb_bf16(const RbParams& p, hipStream_t s) { return launch_rb_bf16_group(&p, 1, s); }
+double rb_bf16_flops(const RbParams& p);
+double rb_bf16_bytes(const RbParams& p);
 const char* launch_resblock_pair(const PairParams& p, hipStream_t s);
 double resblock_pair_flops(const PairParams& p);
 double resblock_pair_bytes(const PairParams& p);
@@ -205,6 +234,9 @@ struct BConvParams {
   const void* in = nullptr;       // [B, T, Cin] channels-last, dense: fp32 (in_bf16 = 0) or bf16 (in_bf16 = 1)
   int in_bf16 = 0;
   float in_slope = 1.0f;          // fp32 input: leaky ReLU applied while staging (1 = identity); a bf16 input is taken as it is
+  const float* in_add[3] = {nullptr, nullptr, nullptr};   // fp32 input: further tensors of the same shape, summed while staging in this order --
+  float in_div = 1.0f;            // x = (((in + in_add[0]) + in_add[1]) + in_add[2]) / in_div: the join of a stage's parallel ResBlocks
+                                  // (reference V/generator.py:44-48: xs / num_kernels) folded into the next layer's input
   const void* wimg = nullptr;     // launch_bf16_image's order
   int KWe = 0;                    // taps the image holds per 32-column tile: KW, or 2 for a polyphase upsampler (tap_split != 0)
   int tap_split = 0;              // polyphase upsampler (KW == 3, packer.polyphase_upsampler): columns < tap_split never use tap 2, columns
@@ -270,7 +302,10 @@ const char* launch_wsola(const int16_t* x, long long n_in, int16_t* out, long lo
 const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, int T, hipStream_t s);
 // wav = tanh(conv7(lrelu_0.01(x))) with Cout = 1; pcm = (int16)(int32)(wav * 32768)
 // act_rows / act_rows_host (optional, device / host copies of the same B values): only samples < act_rows[b] are written (ragged batches)
+// x_add (optional, up to 3 more tensors like x) / x_div: x = (((x + x_add[0]) + x_add[1]) + x_add[2]) / x_div, formed while staging (the
+// join of the last stage's parallel ResBlocks, see BConvParams::in_add)
 const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,
-                             long long N, int C, int KW, hipStream_t s, const int32_t* act_rows = nullptr, const int32_t* act_rows_host = nullptr);
+                             long long N, int C, int KW, hipStream_t s, const int32_t* act_rows = nullptr, const int32_t* act_rows_host = nullptr,
+                             const float* const* x_add = nullptr, float x_div = 1.0f);
 
 }  // namespace e2etts

@@ -652,7 +652,9 @@ template <int TPB>
 __global__ __launch_bounds__(TPB) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ wav,
                                                         int16_t* __restrict__ pcm, long long N, int C, int KW,
-                                                        const int32_t* __restrict__ act_rows, const RowMap rm) {
+                                                        const int32_t* __restrict__ act_rows, const RowMap rm,
+                                                        const float* __restrict__ x2, const float* __restrict__ x3, const float* __restrict__ x4,
+                                                        const float x_div) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ldx = C + 4;
   const int pad = (KW - 1) / 2;
@@ -676,6 +678,14 @@ __global__ __launch_bounds__(TPB) void conv_post_kernel(const float* __restrict_
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t >= 0 && t < N) {
       v = *reinterpret_cast<const float4*>(xb + t * C + c);
+      if (x2) {   // the deferred join of the last stage's ResBlocks: accum_div_kernel's additions and division, in its order
+        const long long o = (long long)b * N * C + t * C + c;
+        const float4 a2 = *reinterpret_cast<const float4*>(x2 + o);
+        v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w;
+        if (x3) { const float4 a3 = *reinterpret_cast<const float4*>(x3 + o); v.x += a3.x; v.y += a3.y; v.z += a3.z; v.w += a3.w; }
+        if (x4) { const float4 a4 = *reinterpret_cast<const float4*>(x4 + o); v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w; }
+        if (x_div != 1.0f) { v.x = v.x / x_div; v.y = v.y / x_div; v.z = v.z / x_div; v.w = v.w / x_div; }
+      }
       v.x = v.x >= 0.f ? v.x : v.x * 0.01f;
       v.y = v.y >= 0.f ? v.y : v.y * 0.01f;
       v.z = v.z >= 0.f ? v.z : v.z * 0.01f;
@@ -931,7 +941,8 @@ const char* launch_transpose_bct_btc(const float* in, float* out, int B, int C, 
 }
 
 const char* launch_conv_post(const float* x, const float* w, const float* bias, float* wav, int16_t* pcm, int B,
-                             long long N, int C, int KW, hipStream_t s, const int32_t* act_rows, const int32_t* act_rows_host) {
+                             long long N, int C, int KW, hipStream_t s, const int32_t* act_rows, const int32_t* act_rows_host,
+                             const float* const* x_add, float x_div) {
   if (!x || !w || !bias) return "conv_post: null pointer";
   if (C % 4 || C <= 0 || C > 128 || KW <= 0 || KW > 15 || !(KW & 1)) return "conv_post: bad dims";
   constexpr int TPB = 256;
@@ -950,7 +961,9 @@ const char* launch_conv_post(const float* x, const float* w, const float* bias, 
     if (rm.cum[B] == 0) return nullptr;
     grid = dim3((unsigned)rm.cum[B]);
   }
-  hipLaunchKernelGGL(conv_post_kernel<TPB>, grid, dim3(TPB), lds, s, x, w, bias, wav, pcm, N, C, KW, act_rows, rm);
+  const float* xa[3] = {x_add ? x_add[0] : nullptr, x_add ? x_add[1] : nullptr, x_add ? x_add[2] : nullptr};
+  if ((xa[1] && !xa[0]) || (xa[2] && !xa[1])) return "conv_post: x_add must be filled from the front";
+  hipLaunchKernelGGL(conv_post_kernel<TPB>, grid, dim3(TPB), lds, s, x, w, bias, wav, pcm, N, C, KW, act_rows, rm, xa[0], xa[1], xa[2], x_div);
   return CHECK_LAUNCH("conv_post");
 }
 

@@ -139,3 +139,49 @@ def test_long_form_60s_stream_bf16():
     # the reference's own bf16 run of this generator (width 512) lies 8.6e-4 from its fp32 output (fixture hifigan_48k w512,
     # test_48k_vocoder_matches_reference_fixture); the engine's bf16 mode must stay inside that distance.  Measured 3.2e-4.
     assert err < 8.6e-4
+
+
+_BF16_CHILD = r"""
+import hashlib, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from e2e_tts_amd import config as cfgmod, synth_weights as sw
+from e2e_tts_amd.models import HifiGan
+cfg = cfgmod.default_config()
+cfg["models"]["hifigan"].update(upsample_rates=[8, 8, 4, 2], upsample_kernel_sizes=[16, 16, 8, 4], upsample_initial_channel=512)
+v = HifiGan(cfg["models"]["hifigan"])
+v.load_state_dict(sw.to_torch(sw.make_vocoder_state(cfg, seed=35)))
+eng = v.eval().to(0).engine
+eng.set_precision("bf16")
+T = 1100
+mel = (0.7 * np.random.Generator(np.random.PCG64(9)).standard_normal((2, T, 80))).astype(np.float32)
+_, whole = eng.vocoder(mel, 2, T, channels_first=False, pcm=True)
+chunks = [np.ascontiguousarray(mel[:, i:i + 300]) for i in range(0, T, 300)]
+stream = np.concatenate(list(eng.vocoder_stream(chunks, 2, want_pcm=True)), axis=1)
+print("SHA", hashlib.sha256(whole.tobytes()).hexdigest(), hashlib.sha256(stream.tobytes()).hexdigest(), int(np.abs(whole.astype(np.int32)).max()))
+"""
+
+
+def test_plain_bf16_kernels_of_round_4_give_round_3s_bits(tmp_path):
+    """Round 4 moved the plain-bf16 vocoder onto conv_bf16.hip (whole-slab convolutions with bf16 hand-over, fused pairs, whole ResBlocks,
+    grouped launches, joins folded into the next layer's staging).  Every one of them claims the arithmetic of the kernels it replaces,
+    term for term: the same utterances, one call and streamed, through the default path and through a child process that switches all
+    of it off (E2ETTS_BCONV / BPAIR / BRB / VOC_GROUP / VOC_DEFER_JOIN = 0: round 3's launches) must give the same PCM bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "bf16_child.py"
+    script.write_text(_BF16_CHILD)
+    shas = []
+    for off in (False, True):
+        env = dict(os.environ)
+        if off:
+            env.update(E2ETTS_BCONV="0", E2ETTS_BPAIR="0", E2ETTS_BRB="0", E2ETTS_VOC_GROUP="0", E2ETTS_VOC_DEFER_JOIN="0")
+        r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "SHA" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("SHA")][0].split()
+        assert line[1] == line[2], "stream != one call"
+        assert int(line[3]) > 1000
+        shas.append(line[1])
+    assert shas[0] == shas[1]

@@ -219,6 +219,81 @@ int main(int argc, char** argv) {
     (void)hipFree(dx); (void)hipFree(db1); (void)hipFree(db2); (void)hipFree(dold); (void)hipFree(dnew); (void)hipFree(dwx1); (void)hipFree(dwx2);
     (void)hipFree(dwf); (void)hipFree(dimg1); (void)hipFree(dimg2);
   }
+  // ---- whole ResBlocks: three pair_bf16 launches (dilations 1, 3, 5) against one rb_bf16 launch, bit for bit, both timed
+  struct RShape { const char* name; int rows_per_frame, C, KW; bool acc; };
+  RShape rshapes[] = {{"rb s3 k3", 256, 64, 3, false}, {"rb s3 k7", 256, 64, 7, false}, {"rb s3 k11+a", 256, 64, 11, true},
+                      {"rb s4 k3", 512, 32, 3, false}, {"rb s4 k7+a", 512, 32, 7, true}, {"rb s4 k11", 512, 32, 11, false}};
+  for (auto& c : rshapes) {
+    if (filter && !strstr(c.name, filter)) continue;
+    const int T = frames * c.rows_per_frame;
+    const int dils[3] = {1, 3, 5};
+    const size_t nx = (size_t)T * c.C, nw = (size_t)c.C * c.KW * c.C;
+    std::vector<float> hx(nx), hs(nx);
+    fill(hx, 21); fill(hs, 22);
+    float *dx, *da, *dbb, *dold, *dnew, *dbias;
+    CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&da, nx * 4)); CK(hipMalloc(&dbb, nx * 4)); CK(hipMalloc(&dold, nx * 4)); CK(hipMalloc(&dnew, nx * 4));
+    CK(hipMalloc(&dbias, 6 * c.C * 4));
+    CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dold, hs.data(), nx * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dnew, hs.data(), nx * 4, hipMemcpyHostToDevice));
+    void* img[3][2]; float* wx[3][2];
+    for (int m = 0; m < 3; ++m) for (int h = 0; h < 2; ++h) {
+      std::vector<float> hw(nw), hb(c.C);
+      fill(hw, 30 + 2 * m + h); fill(hb, 40 + 2 * m + h);
+      for (auto& x : hw) x *= 0.05f;
+      auto px = pack_x3(hw, c.C, c.KW, c.C);
+      CK(hipMalloc(&wx[m][h], px.size() * 4)); CK(hipMemcpy(wx[m][h], px.data(), px.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMalloc(&img[m][h], bf16_image_bytes(c.C, c.KW, c.C, 0)));
+      const char* m0 = launch_bf16_image(wx[m][h], img[m][h], c.C, c.KW, c.C, 0, s);
+      if (m0) { printf("%s: %s\n", c.name, m0); return 1; }
+      CK(hipMemcpy(dbias + (2 * m + h) * c.C, hb.data(), c.C * 4, hipMemcpyHostToDevice));
+    }
+    PairParams q[3];
+    for (int m = 0; m < 3; ++m) {
+      q[m] = PairParams();
+      q[m].x = m == 0 ? dx : (m == 1 ? da : dbb); q[m].out = m == 0 ? da : (m == 1 ? dbb : dold);
+      q[m].b1 = dbias + (2 * m) * c.C; q[m].b2 = dbias + (2 * m + 1) * c.C; q[m].bimg1 = img[m][0]; q[m].bimg2 = img[m][1];
+      q[m].B = 1; q[m].T = T; q[m].C = c.C; q[m].KW = c.KW; q[m].dil = dils[m]; q[m].x_bs = q[m].out_bs = (long long)T * c.C; q[m].slope = 0.1f; q[m].mode = 2;
+    }
+    q[2].accumulate = c.acc; q[2].out_div = c.acc ? 3.0f : 1.0f;
+    RbParams r; r.x = dx; r.out = dnew; r.n_pairs = 3; r.B = 1; r.T = T; r.C = c.C; r.KW = c.KW; r.x_bs = r.out_bs = (long long)T * c.C; r.slope = 0.1f;
+    r.accumulate = c.acc; r.out_div = c.acc ? 3.0f : 1.0f;
+    for (int m = 0; m < 3; ++m) { r.bimg[m][0] = img[m][0]; r.bimg[m][1] = img[m][1]; r.b1[m] = q[m].b1; r.b2[m] = q[m].b2; r.dil[m] = dils[m]; }
+    if (!rb_bf16_supported(r)) { printf("%-16s not supported by rb_bf16\n", c.name); continue; }
+    const char* m = nullptr;
+    for (int k = 0; k < 3 && !m; ++k) m = launch_pair_bf16(q[k], s);
+    if (!m) m = launch_rb_bf16(r, s);
+    if (m) { printf("%s: %s\n", c.name, m); return 1; }
+    CK(hipStreamSynchronize(s));
+    std::vector<float> a(nx), o(nx);
+    CK(hipMemcpy(a.data(), dnew, nx * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(o.data(), dold, nx * 4, hipMemcpyDeviceToHost));
+    size_t ndiff = 0, first = 0; double maxd = 0, maxv = 0;
+    for (size_t i = 0; i < nx; ++i) {
+      if (memcmp(&a[i], &o[i], 4)) { if (!ndiff) first = i; ++ndiff; maxd = fmax(maxd, fabs((double)a[i] - o[i])); }
+      maxv = fmax(maxv, fabs((double)o[i]));
+    }
+    q[2].accumulate = r.accumulate = 0; q[2].out_div = r.out_div = 1.0f;
+    float ms_old, ms_new;
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) for (int k = 0; k < 3; ++k) launch_pair_bf16(q[k], s);
+    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_old, e0, e1));
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) launch_rb_bf16(r, s);
+    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_new, e0, e1));
+#ifdef E2ETTS_BC_DIAG
+    { unsigned long long d[8]; conv_bf16_read_diag(d);
+      const char* nm[7] = {"guards + x0 + image", "conv1 (3 pairs)", "image I + barriers (3)", "conv2 (3)", "x update + image X (3)", "store", "whole"};
+      printf("   diag (cycles per workgroup, wave 0; %llu workgroups):", d[7]);
+      for (int i = 0; i < 7; ++i) printf(" %s=%.0f", nm[i], (double)d[i] / (double)(d[7] ? d[7] : 1));
+      printf("\n"); }
+#endif
+    const double fl = 3 * 2.0 * 2.0 * T * c.C * (double)c.C * c.KW;
+    printf("%-16s T=%7d | 3 x pair_bf16 %7.1f us %7.1f TFLOP/s | rb_bf16 %7.1f us %7.1f TFLOP/s | %zu differing of %zu (first at row %zu, max |d| %.3g, max |v| %.3g)%s\n",
+           c.name, T, ms_old / reps * 1e3, fl / (ms_old / reps) / 1e9, ms_new / reps * 1e3, fl / (ms_new / reps) / 1e9, ndiff, nx, first / c.C, maxd, maxv,
+           ndiff ? "  MISMATCH" : "");
+    bad += ndiff ? 1 : 0;
+    (void)hipFree(dx); (void)hipFree(da); (void)hipFree(dbb); (void)hipFree(dold); (void)hipFree(dnew); (void)hipFree(dbias);
+    for (int mm = 0; mm < 3; ++mm) for (int h = 0; h < 2; ++h) { (void)hipFree(wx[mm][h]); (void)hipFree(img[mm][h]); }
+  }
   printf(bad ? "FAILED: %d shapes differ\n" : "all shapes bit-identical\n", bad);
   return bad ? 1 : 0;
 }

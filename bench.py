@@ -54,8 +54,10 @@ BATCH = 32
 PHONEMES = 128
 FRAMES_PER_PHONEME = 6
 
-CONV_CLASSES = ("conv_gemm", "conv_x3", "resblock", "x3 ", "f32 ", "pair ")  # the last three: per-layer classes under E2ETTS_PROFILE_FINE=1
-X3_CLASSES = ("conv_x3", "resblock", "x3 ", "pair ")
+# (conv_bf16 / pair_bf16 / rb_bf16: the plain-bf16 kernels of conv_bf16.hip, BASELINE config 5; "x3 " / "f32 " / "pair ": per-layer classes
+# under E2ETTS_PROFILE_FINE=1)
+CONV_CLASSES = ("conv_gemm", "conv_x3", "conv_bf16", "pair_bf16", "rb_bf16", "resblock", "x3 ", "f32 ", "pair ")
+X3_CLASSES = ("conv_x3", "conv_bf16", "pair_bf16", "rb_bf16", "resblock", "x3 ", "pair ")
 
 
 def log(*a):
@@ -216,47 +218,55 @@ def cpu_baseline(cfg, stats, ac_state, voc_state, ids_batch):
     b1 = {"value": samples / med, "shape": f"C2: B=1 L={L} -> {samples} samples", "threads": best[1], "backend": name[best[0]],
           "median_s": round(med, 3), "min_max_s": [round(min(runs), 3), round(max(runs), 3)], "runs": CPU_RUNS, "warmups": CPU_WARMUPS,
           "probe_s": {f"{b}@{t}": round(v, 3) for (b, t), v in probe.items()}}
-    # ---- leg batch.  (a) one padded batch on all usable CPUs; (b) the same utterances as independent tasks, W workers x t threads
+    # ---- legs batch (headline shape) and c3 (BASELINE config 3's mixed lengths), both bounded to CPU_BATCH utterances standing in for the
+    # B = 32 batches, both as independent single-utterance tasks over a pool of W workers x t threads (round 3 also timed the padded batch
+    # as ONE call on every usable CPU: 11-14 s against 4-5.5 s, always the loser, and a third of this function's time -- dropped)
     nb = min(CPU_BATCH, ids_batch.shape[0])
-    batch_ids = np.ascontiguousarray(ids_batch[:nb])
-    legs = {}
-    dt0, bs = run(batch_ids, best[0], usable)      # warm-up of the batch shapes
-    t_whole = [run(batch_ids, best[0], usable)[0] for _ in range(CPU_BATCH_RUNS)] if dt0 < 40 else [dt0]
-    legs["one_call"] = {"threads": usable, "median_s": round(statistics.median(t_whole), 3)}
     per_task = max(1, min(best[1], max(usable // 2, 1)))   # at least two workers when there are two CPUs
     workers = max(1, min(nb, usable // per_task))
 
-    def pool_run():
-        orc.set_conv_backend(best[0])
-        torch.set_num_threads(per_task)
-        lens1 = np.full((1,), L, np.int64)
+    def pool_leg(id_rows, shape):
+        """id_rows: list of 1-D id arrays (one utterance each, unpadded)."""
+        def once():
+            orc.set_conv_backend(best[0])
+            torch.set_num_threads(per_task)
 
-        def task(i):
-            (mel, mel_post, dur), ml = ac.inference(np.array([1]), batch_ids[i:i + 1], lens1)
-            voc.forward(mel_post.transpose(0, 2, 1))
-            return int(ml[0]) * hop
-        with threadpool_limits(limits=per_task):
-            t0 = time.perf_counter()
-            with ThreadPoolExecutor(workers) as ex:
-                n = sum(ex.map(task, range(nb)))
-            return time.perf_counter() - t0, n
-    if workers > 1:
-        pool_run()
-        t_pool = [pool_run()[0] for _ in range(CPU_BATCH_RUNS)]
-        legs["independent_tasks"] = {"workers": workers, "threads_per_task": per_task, "threads": workers * per_task,
-                                     "median_s": round(statistics.median(t_pool), 3)}
+            def task(ids1):
+                n = int(ids1.shape[0])
+                (mel, mel_post, dur), ml = ac.inference(np.array([1]), ids1.reshape(1, n), np.full((1,), n, np.int64))
+                voc.forward(mel_post.transpose(0, 2, 1))
+                return int(ml[0]) * hop
+            with threadpool_limits(limits=per_task):
+                t0 = time.perf_counter()
+                with ThreadPoolExecutor(workers) as ex:
+                    n = sum(ex.map(task, id_rows))
+                return time.perf_counter() - t0, n
+        once()   # warm-up of these shapes
+        ts, n = [], 0
+        for _ in range(CPU_BATCH_RUNS):
+            dt, n = once()
+            ts.append(dt)
+        med = statistics.median(ts)
+        return {"value": n / med, "shape": shape, "form": "independent_tasks", "workers": workers, "threads_per_task": per_task,
+                "threads": workers * per_task, "median_s": round(med, 3), "runs": CPU_BATCH_RUNS, "warmups": 1, "samples": n,
+                "backend": name[best[0]]}
+
+    batch = pool_leg([np.ascontiguousarray(ids_batch[i]) for i in range(nb)],
+                     f"{nb} utterances of the headline batch (fixed L = {L}), standing in for B = {ids_batch.shape[0]}")
+    # config 3: the first CPU_BATCH utterances of the shuffled length list (40 .. 200 phonemes), ids drawn like the GPU leg's
+    c3_lens = mixed_lengths(BATCH)[:nb]
+    rng = np.random.Generator(np.random.PCG64(3))
+    c3 = pool_leg([rng.integers(4, 131, size=int(n)).astype(np.int64) for n in c3_lens],
+                  f"{nb} utterances of config 3's batch (lengths {', '.join(str(int(n)) for n in c3_lens)} of the 40 .. 200 list), standing in for B = {BATCH}")
     orc.set_conv_backend(None)
-    bname = min(legs, key=lambda k: legs[k]["median_s"])
-    batch = {"value": bs / legs[bname]["median_s"], "shape": f"B={nb} of the headline batch, fixed L={L} -> {bs} samples", "form": bname,
-             "threads": legs[bname]["threads"], "runs": CPU_BATCH_RUNS, "warmups": 1, "legs": legs, "backend": name[best[0]]}
-    top = b1 if b1["value"] >= batch["value"] else batch
+    top = max((b1, batch, c3), key=lambda leg: leg["value"])
     sr = cfg["audio"]["signal"]["sampling_rate"]
     return {"value": top["value"], "unit": "audio samples/s", "cores": top["threads"], "kind": "port",
             "threads": f"{top['threads']} of {usable} usable CPUs ({why}; {ncpu} logical on the host)",
-            "sample": (f"oracle ({top['backend']}); better of b1 [{b1['shape']}; {CPU_WARMUPS}+ warm-ups, median of {CPU_RUNS} = {b1['median_s']} s on "
-                       f"{b1['threads']} threads] and batch [{batch['shape']}; form {batch['form']}, median of {CPU_BATCH_RUNS} = "
-                       f"{legs[bname]['median_s']} s on {batch['threads']} threads]"),
-            "b1": b1, "batch": batch, "usable_cpus": usable, "real_time_factor": top["value"] / sr}
+            "sample": (f"oracle ({top['backend']}); best of three bounded legs -- b1 [{b1['shape']}; {CPU_WARMUPS}+ warm-ups, median of {CPU_RUNS} = "
+                       f"{b1['median_s']} s on {b1['threads']} threads], batch [{batch['shape']}; median of {CPU_BATCH_RUNS} = {batch['median_s']} s "
+                       f"on {batch['threads']} threads] and c3 [{c3['shape']}; {c3['median_s']} s on {c3['threads']} threads]"),
+            "b1": b1, "batch": batch, "c3": c3, "usable_cpus": usable, "real_time_factor": top["value"] / sr}
 
 
 # ------------------------------------------------------------------------------------------------ stub engine (tests only)
@@ -810,6 +820,12 @@ def c5_longform(torch, traffic_json):
     rec = {"workload": f"48 kHz HiFi-GAN (8x8x4x2, hop 512, width 512), 1 utterance of {C5_FRAMES} frames = {C5_FRAMES * 512 / 48000:.2f} s, "
                        f"streamed in chunks of {C5_CHUNK} frames, PCM fetched per chunk; mel resident on the host", "sample_rate": 48000}
 
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_c5.json")) as fh:
+            c5_traffic = json.load(fh)
+    except (OSError, ValueError):
+        c5_traffic = {}
+
     def one_chunk_size(chunk, table_tag):
         chunks = [np.ascontiguousarray(mel[:, i:i + chunk]) for i in range(0, C5_FRAMES, chunk)]
         run = lambda: sum(p.shape[1] for p in eng.vocoder_stream(chunks, 1, want_pcm=True))
@@ -835,7 +851,8 @@ def c5_longform(torch, traffic_json):
             conv = [s for s in st if s["name"].startswith(CONV_CLASSES)]
             rl["all_conv_tflops"] = round(sum(s["flops"] for s in conv) / max(sum(s["ms"] for s in conv) * 1e-3, 1e-9) / 1e12, 3)
             rl["kernel_ms_per_pass"] = round(sum(s["ms"] for s in st), 3)
-            rl["traffic"] = None
+            # HBM bytes per launch of that class from the PMC passes of tools/profile_c5.sh (chunk 512, plain bf16), when they cover it
+            rl["traffic"] = c5_traffic.get(dom["name"], {}).get("hbm_bytes_per_launch") if (prec == "bf16" and chunk == C5_CHUNK) else None
             if prec == "bf16" and table_tag:
                 class_table(st, 1, table_tag)
             res[prec] = {"ms": dt * 1e3, "real_time_factor": n / 48000 / dt, "samples_per_s": n / dt, "roofline": rl}

@@ -90,7 +90,7 @@ __device__ __forceinline__ void bc_pipeline() {
 // batch is a round trip to L2 / HBM with the CU otherwise idle: 6-piece batches took 8 600 cycles for a 178-row x 256-channel slab).
 // in_add / in_div (fp32 input only): further tensors summed into the input while staging -- x = (((in + a0) + a1) + a2) / div, the order and
 // operations of accum_div_kernel (small_kernels.hip), whose launch and whose pass over the tensors this replaces.
-template <bool IN_BF16, int SB>
+template <bool IN_BF16, int SB, int NTHR = 256>
 __device__ __forceinline__ void bc_stage(unsigned char* smem, const void* in_utt, const int T, const int Cin, const int NCH, const int RS,
                                          const int t_first, const int srows, const float slope, const int tid,
                                          const float* a0 = nullptr, const float* a1 = nullptr, const float* a2 = nullptr, const float div = 1.0f) {
@@ -106,13 +106,13 @@ __device__ __forceinline__ void bc_stage(unsigned char* smem, const void* in_utt
       const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a0), 0, bytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a1 ? a1 : a0), 0, bytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a2 ? a2 : a0), 0, bytes, 0x00020000);
-      for (int base = tid; base < npieces; base += 256 * SJ) {
+      for (int base = tid; base < npieces; base += NTHR * SJ) {
         float4 v[SJ][2], w0[SJ][2], w1[SJ][2], w2[SJ][2];
         bool ok[SJ];
         int dst[SJ];
 #pragma unroll
         for (int i = 0; i < SJ; ++i) {
-          const int idx = base + i * 256;
+          const int idx = base + i * NTHR;
           const int row = idx / ppr, pc = idx - row * ppr;
           const int t = t_first + row;
           ok[i] = idx < npieces && t >= 0 && t < T && pc * 8 < Cin;
@@ -148,13 +148,13 @@ __device__ __forceinline__ void bc_stage(unsigned char* smem, const void* in_utt
       return;
     }
   }
-  for (int base = tid; base < npieces; base += 256 * SB) {
+  for (int base = tid; base < npieces; base += NTHR * SB) {
     float4 ra[SB], rb[SB];
     bool ok[SB];
     int dst[SB];
 #pragma unroll
     for (int i = 0; i < SB; ++i) {
-      const int idx = base + i * 256;
+      const int idx = base + i * NTHR;
       const int row = idx / ppr, pc = idx - row * ppr;
       const int t = t_first + row;
       ok[i] = idx < npieces && t >= 0 && t < T && pc * 8 < Cin;
@@ -441,8 +441,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const BConvGroup grp)
 // two per 32-channel chunk of conv1 alone), 128-position x 32-channel wavefront tiles (MT = 4: one 1-KiB weight fragment per four MFMAs,
 // half of what the L1 can deliver), the weights of conv2's first D units requested before conv1's epilogue.
 template <int MT, int WGM, int WGN, int D, bool ACCUM>
-__global__ __launch_bounds__(256, 2) void pair_bf16_kernel(const BPairGroup grp) {
-  static_assert(WGM * WGN == 4, "four wavefronts per workgroup");
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void pair_bf16_kernel(const BPairGroup grp) {
+  static_assert(WGM * WGN == 4 || WGM * WGN == 8, "four or eight wavefronts per workgroup (eight: 256 channels, one workgroup per CU)");
+  constexpr int NTHR = 64 * WGM * WGN;
   int member = 0;
   for (int k = 0; k + 1 < grp.n; ++k) member += (int)blockIdx.x >= grp.wg_end[k] ? 1 : 0;
   const PairParams& p = grp.p[member];
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void pair_bf16_kernel(const BPairGroup grp)
   E2ETTS_BC_RING_FILL(w1_rsrc, nt0, NU)
   const float* x_b = p.x + (long long)b * p.x_bs;
   float* out_b = p.out + (long long)b * p.out_bs;
-  bc_stage<false, 12>(smem, x_b, p.T, C, NCH, RS, i0 - pad1, BMI + halo1, p.slope, tid);
+  bc_stage<false, (NTHR == 512 ? 8 : 12), NTHR>(smem, x_b, p.T, C, NCH, RS, i0 - pad1, BMI + halo1, p.slope, tid);
   BC_STAMP(st1);
   __syncthreads();   // slab visible
   BC_STAMP(st2);
@@ -999,7 +1000,7 @@ const char* pb_launch(const PairParams* ps, int n, hipStream_t s) {
   constexpr int BMI = 32 * MT * WGM, RS = WGN * 64 + 16;
   BPairGroup g;
   g.n = n;
-  size_t lds = (size_t)4 * 32 * 36 * 4;
+  size_t lds = (size_t)WGM * WGN * 32 * 36 * 4;
   long long nwg = 0;
   bool any_acc = false;
   for (int k = 0; k < n; ++k) {
@@ -1020,14 +1021,14 @@ const char* pb_launch(const PairParams* ps, int n, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_bf16_kernel<MT, WGM, WGN, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  if (any_acc) hipLaunchKernelGGL((pair_bf16_kernel<MT, WGM, WGN, D, true>), dim3((unsigned)nwg), dim3(256), lds, s, g);
-  else hipLaunchKernelGGL((pair_bf16_kernel<MT, WGM, WGN, D, false>), dim3((unsigned)nwg), dim3(256), lds, s, g);
+  if (any_acc) hipLaunchKernelGGL((pair_bf16_kernel<MT, WGM, WGN, D, true>), dim3((unsigned)nwg), dim3(64 * WGM * WGN), lds, s, g);
+  else hipLaunchKernelGGL((pair_bf16_kernel<MT, WGM, WGN, D, false>), dim3((unsigned)nwg), dim3(64 * WGM * WGN), lds, s, g);
   return hipGetLastError() == hipSuccess ? nullptr : "pair_bf16: launch failed";
 }
 
 // position blocks per wavefront: 4 (128 x 32 wavefront tiles) unless that leaves the launch under ~half a round of workgroups
 long long pb_tiles4(const PairParams& p) {
-  const int wgm = 4 / (p.C / 32);
+  const int wgm = p.C >= 128 ? 1 : 4 / (p.C / 32);
   return (long long)p.B * ((p.T + 128 * wgm - p.KW) / (128 * wgm - (p.KW - 1)));
 }
 int pb_mt(long long tiles4) {
@@ -1041,7 +1042,9 @@ int pb_mt(long long tiles4) {
 bool pair_bf16_supported(const PairParams& p) {
   static const bool on = !(getenv("E2ETTS_BPAIR") && atoi(getenv("E2ETTS_BPAIR")) == 0);   // tuning aid: 0 keeps resblock_pair.hip
   if (!on || p.mode != 2 || !p.bimg1 || !p.bimg2 || p.act_rows) return false;
-  if (!(p.C == 32 || p.C == 64 || p.C == 128) || !(p.KW & 1) || p.KW < 3 || p.KW > 15 || p.dil < 1 || p.dil * (p.KW - 1) > BC_MAX_HALO) return false;
+  if (!(p.C == 32 || p.C == 64 || p.C == 128 || p.C == 256) || !(p.KW & 1) || p.KW < 3 || p.KW > 15 || p.dil < 1 || p.dil * (p.KW - 1) > BC_MAX_HALO) return false;
+  static const bool on256 = !(getenv("E2ETTS_BPAIR256") && atoi(getenv("E2ETTS_BPAIR256")) == 0);   // tuning aid
+  if (p.C == 256 && !on256) return false;
   if (p.x_bs != (long long)p.T * p.C || p.out_bs != (long long)p.T * p.C) return false;
   return (long long)p.T * p.C * 4 < (1LL << 31);
 }
@@ -1062,6 +1065,11 @@ const char* launch_pair_bf16_group(const PairParams* ps, int n, hipStream_t s) {
   }
   const int mt = pb_mt(tiles4);
   const int C = ps[0].C;
+  // 256 channels: eight wavefronts side by side on the channels, one workgroup per CU (the slab alone is 60-94 KB); 64-position blocks
+  // per wavefront while the launch has fewer tiles than CUs (a 542-frame window: 226 tiles of 64 rows for the three kernel sizes together)
+  // (same-box A/B at a 542-frame window, whole pass: 64-position blocks 10.64 ms, 128-position blocks 10.95, two convolution launches 10.76)
+  static const int mt256 = getenv("E2ETTS_BPAIR256_MT") ? atoi(getenv("E2ETTS_BPAIR256_MT")) : 0;   // tuning aid (0: by grid size)
+  if (C == 256) return (mt256 == 4 || (mt256 == 0 && tiles4 >= 512)) ? pb_launch<4, 1, 8, 6>(ps, n, s) : pb_launch<2, 1, 8, 8>(ps, n, s);
   if (C == 128) return mt == 4 ? pb_launch<4, 1, 4, 6>(ps, n, s) : pb_launch<2, 1, 4, 8>(ps, n, s);
   if (C == 64) return mt == 4 ? pb_launch<4, 2, 2, 6>(ps, n, s) : pb_launch<2, 2, 2, 8>(ps, n, s);
   return mt == 4 ? pb_launch<4, 4, 1, 6>(ps, n, s) : pb_launch<2, 4, 1, 8>(ps, n, s);

@@ -1284,7 +1284,14 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
         order[j] = j;
       }
       std::sort(order, order + nk, [&](int a, int b2) { return c.voc_rb_kernel[a] > c.voc_rb_kernel[b2]; });
-      const bool as_pairs = co <= 128;
+      bool as_pairs = co <= 128;
+      if (co == 256) {   // fused pairs at 256 channels too where conv_bf16.hip has them (eight-wavefront workgroups)
+        PairParams q;
+        q.x = XU; q.out = Sj[0]; q.B = B; q.T = (int)n; q.C = co; q.KW = c.voc_rb_kernel[0]; q.dil = 1; q.x_bs = q.out_bs = (long long)n * co; q.mode = 2;
+        const int idx0 = i * nk;
+        auto i1 = e->bimg_of.find(e->rb_c1[idx0][0].wx3), i2 = e->bimg_of.find(e->rb_c2[idx0][0].wx3);
+        if (i1 != e->bimg_of.end() && i2 != e->bimg_of.end()) { q.bimg1 = i1->second.first; q.bimg2 = i2->second.first; as_pairs = pair_bf16_supported(q); }
+      }
       // 32 / 64 channels: the WHOLE ResBlock of every kernel size in one launch (these stages' tensors, 35 MB per 542-frame window at 48 kHz,
       // stream through the Infinity Cache: pair by pair each is read twice and written once per pair)
       {

@@ -154,7 +154,8 @@ int main(int argc, char** argv) {
   }
   // ---- fused pairs: resblock_pair (mode 2) against pair_bf16, bit for bit, and both timed
   struct PShape { const char* name; int rows_per_frame, C, KW, dil; bool acc; };
-  PShape pshapes[] = {{"pair s2 k3d1", 64, 128, 3, 1, false}, {"pair s2 k7d3", 64, 128, 7, 3, false}, {"pair s2 k11d5+a", 64, 128, 11, 5, true},
+  PShape pshapes[] = {{"pair s1 k3d1", 8, 256, 3, 1, false}, {"pair s1 k7d3+a", 8, 256, 7, 3, true}, {"pair s1 k11d5", 8, 256, 11, 5, false},
+                      {"pair s2 k3d1", 64, 128, 3, 1, false}, {"pair s2 k7d3", 64, 128, 7, 3, false}, {"pair s2 k11d5+a", 64, 128, 11, 5, true},
                       {"pair s3 k7d1", 256, 64, 7, 1, false}, {"pair s3 k11d5+a", 256, 64, 11, 5, true}, {"pair s3 k3d3", 256, 64, 3, 3, false},
                       {"pair s4 k7d3", 512, 32, 7, 3, false}, {"pair s4 k11d1", 512, 32, 11, 1, false}, {"pair s4 k11d5+a", 512, 32, 11, 5, true}};
   for (auto& c : pshapes) {

@@ -34,6 +34,18 @@ def kernel_class(name: str):
     m = re.search(r"resblock_chain_kernel<\d+, (\d+)", name)
     if m:
         return "resblock_chain_" + m.group(1)
+    # conv_bf16.hip (plain bf16): <MT, NT, WGM, WGN, ...> -> rows x columns of the workgroup tile; the fused forms by their channel count
+    # (32 x WGN).  In the 48 kHz stream's windows the pairs and whole ResBlocks run as grouped launches: the engine's class names.
+    m = re.search(r"conv_bf16_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        mt, nt, wgm, wgn = (int(x) for x in m.groups())
+        return f"conv_bf16_{32 * mt * wgm}x{32 * nt * wgn}"
+    m = re.search(r"pair_bf16_kernel<\d+, \d+, (\d+)", name)
+    if m:
+        return f"pair_bf16_group_{32 * int(m.group(1))}"
+    m = re.search(r"rb_bf16_kernel<\d+, \d+, (\d+)", name)
+    if m:
+        return f"rb_bf16_group_{32 * int(m.group(1))}"
     m = re.search(r"conv_rows_kernel<\d+, (\d+), \d+, (true|false|1|0)", name)
     if m:  # SPLITK: the phoneme-level K-split form; otherwise the few-rows form of conv_gemm's arithmetic
         if m.group(2) in ("true", "1"):
@@ -56,6 +68,11 @@ def main():
     # --name FILE.md: write the table under that name and leave profiles/pmc_traffic.json (bench.py's `roofline.traffic` source, which
     # belongs to the headline workload) alone -- for side workloads such as `bench.py --blocks conformer`
     name = sys.argv[sys.argv.index("--name") + 1] if "--name" in sys.argv else None
+    # --traffic FILE.json: with --name, ALSO write the per-class clock / MFMA busy / HBM bytes as JSON under that name next to
+    # pmc_traffic.json (profiles/pmc_traffic_c5.json is what bench.py's c5_longform leg reads for `roofline.traffic`)
+    traffic_name = sys.argv[sys.argv.index("--traffic") + 1] if "--traffic" in sys.argv else None
+    # --cmd "...": the profiled command line, for the table's header (default: bench.py with --args)
+    cmd = sys.argv[sys.argv.index("--cmd") + 1] if "--cmd" in sys.argv else None
     counters = defaultdict(lambda: defaultdict(float))   # class -> counter -> sum over dispatches
     ndisp = defaultdict(lambda: defaultdict(int))        # class -> counter -> dispatches seen
     dur_ns = defaultdict(float)
@@ -79,7 +96,8 @@ def main():
         sys.exit(f"no counter_collection.csv with known kernels under {src}")
     os.makedirs(dst, exist_ok=True)
     traffic = {}
-    what = (f"Separate `rocprofv3 --pmc` passes of `python3 bench.py {extra} --steps 2 --warmup 1 --no-cpu-baseline --no-extras` -- counters only, no"
+    what = (f"Separate `rocprofv3 --pmc` passes of `{cmd}` -- counters only, no" if cmd else
+            f"Separate `rocprofv3 --pmc` passes of `python3 bench.py {extra} --steps 2 --warmup 1 --no-cpu-baseline --no-extras` -- counters only, no"
             if extra else
             "Separate `rocprofv3 --pmc` passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` -- once in the default\n"
             "exact-fp32 arithmetic (classes conv_gemm_*) and once with `--precision bf16x3` (classes conv_x3_*, resblock_*) -- counters only, no")
@@ -114,8 +132,8 @@ def main():
         traffic[cls] = entry
     with open(os.path.join(dst, name or "pmc_summary.md"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
-    if name is None:
-        with open(os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_traffic.json"), "w") as fh:
+    if name is None or traffic_name:
+        with open(os.path.join(os.path.dirname(os.path.abspath(dst)), traffic_name or "pmc_traffic.json"), "w") as fh:
             json.dump(traffic, fh, indent=1)
     print("\n".join(lines))
 

@@ -610,10 +610,16 @@ struct BRbGroup {
   int n;
   int wg_end[BC_GROUP_MAX];
   int rtiles[BC_GROUP_MAX];
+  int st_H, st_gx, st_hk;   // STAGE form: the tile geometry all members share (the maxima over them)
   RbParams p[BC_GROUP_MAX];
 };
 
-template <int MT, int WGM, int WGN, int D, bool ACCUM>
+// STAGE: ONE workgroup computes ALL the group's ResBlocks on its tile, one after the other, from the x_0 it loaded once, and writes their
+// sum / n: the whole `xs / num_kernels` of reference V/generator.py:44-48 in one launch, with the additions in accum_div's order
+// ((S_0 + S_1) + S_2) / n, so the bits are those of the separate launches + join.  Per stage the activations then cross the memory system
+// twice (x in, sum out) instead of nine times (x in three times, three partial sums out, three in again at the join or in the next layer's
+// staging) -- which is what the 32-channel stage of a 48 kHz window (35 MB per tensor) spends its time on.
+template <int MT, int WGM, int WGN, int D, bool ACCUM, bool STAGE>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void rb_bf16_kernel(const BRbGroup grp) {
   constexpr int NT = 1;
   constexpr int NWAVE = WGM * WGN, NTHR = 64 * NWAVE;
@@ -624,8 +630,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void rb_bf16_kerne
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   int member = 0;
-  for (int k = 0; k + 1 < grp.n; ++k) member += (int)blockIdx.x >= grp.wg_end[k] ? 1 : 0;
-  const RbParams& p = grp.p[member];
+  if constexpr (!STAGE)
+    for (int k = 0; k + 1 < grp.n; ++k) member += (int)blockIdx.x >= grp.wg_end[k] ? 1 : 0;
   const int bid = (int)blockIdx.x - (member ? grp.wg_end[member - 1] : 0);
   const int rtiles = grp.rtiles[member];
 
@@ -633,32 +639,40 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void rb_bf16_kerne
   const int wm = wave / WGN, wn = wave % WGN;
   const int li = lane & 31, lh = lane >> 5;
   const int b = bid / rtiles, tile = bid - b * rtiles;
-  const int KW = p.KW, hk = (KW - 1) / 2, NP = p.n_pairs;
-  int H = 0, gx = 0;
-  for (int m = 0; m < NP; ++m) {
-    H += hk * (p.dil[m] + 1);
-    gx = max(gx, hk * p.dil[m]);
+  // tile geometry: H positions per edge are lost to the receptive field, X has gx guard rows of zeros at either end, I has hkI
+  int H = 0, gx = 0, hkI = 0;
+  if constexpr (STAGE) {
+    H = grp.st_H; gx = grp.st_gx; hkI = grp.st_hk;
+  } else {
+    const RbParams& p0 = grp.p[member];
+    hkI = (p0.KW - 1) / 2;
+    for (int m = 0; m < p0.n_pairs; ++m) {
+      H += hkI * (p0.dil[m] + 1);
+      gx = max(gx, hkI * p0.dil[m]);
+    }
   }
+  const int T = grp.p[member].T;
   const int RO = R - 2 * H;             // valid output positions per tile
   const int xrows = R + 2 * gx;
   unsigned char* Xs = smem;
   unsigned char* Is = smem + xrows * RS;
   const int origin = tile * RO - H;     // global position of tile row 0
-  const int NU = NCH * KW;
   const int nt0 = wn;
-  const float* x_b = p.x + (long long)b * p.x_bs;
-  float* out_b = p.out + (long long)b * p.out_bs;
+  const float* x_b = grp.p[member].x + (long long)b * grp.p[member].x_bs;
+  float* out_b = grp.p[member].out + (long long)b * grp.p[member].out_bs;
 
   unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, sc1 = 0, se1 = 0, sc2 = 0, se2 = 0;
   BC_STAMP(d0);
   uint4 wr[D][2][NT];
   bf16x8 xb[2][2][MT];
   f32x16 acc[MT][NT], xres[MT];
+  f32x16 x0[STAGE ? MT : 1], sum[STAGE ? MT : 1];
   E2ETTS_BC_LAMBDAS
   // the first convolution's first D units
   {
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[0][0]), 0, NCH * NU * 2048, 0x00020000);
-    E2ETTS_BC_RING_FILL(w_rsrc, nt0, NU)
+    const RbParams& pf = grp.p[member];
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pf.bimg[0][0]), 0, NCH * (NCH * pf.KW) * 2048, 0x00020000);
+    E2ETTS_BC_RING_FILL(w_rsrc, nt0, NCH * pf.KW)
   }
   // ---- zero the guard rows of both images (never written again)
   for (int i = tid; i < 2 * gx * (RS / 16); i += NTHR) {
@@ -666,9 +680,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void rb_bf16_kerne
     const int row = r < gx ? r : R + r;   // rows [0, gx) and [R + gx, R + 2 gx)
     *reinterpret_cast<uint4*>(Xs + row * RS + c16 * 16) = make_uint4(0, 0, 0, 0);
   }
-  for (int i = tid; i < 2 * hk * (RS / 16); i += NTHR) {
+  for (int i = tid; i < 2 * hkI * (RS / 16); i += NTHR) {
     const int r = i / (RS / 16), c16 = i - r * (RS / 16);
-    const int row = r < hk ? r : R + r;
+    const int row = r < hkI ? r : R + r;
     *reinterpret_cast<uint4*>(Is + row * RS + c16 * 16) = make_uint4(0, 0, 0, 0);
   }
   // ---- x_0 into registers: lane (li, lh) = position li of the block, register 4 q + i = channel 8 q + 4 lh + i of the wavefront's 32.
@@ -680,15 +694,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void rb_bf16_kerne
   constexpr int LPR = 8, RPP = 8, PASSES = 4;
   const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
   {
-    float* patch = reinterpret_cast<float*>(Is + hk * RS) + wave * (32 * ELD);
+    float* patch = reinterpret_cast<float*>(Is + hkI * RS) + wave * (32 * ELD);
     float4 rowv[MT][PASSES];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
         const int g = origin + wm * (32 * MT) + m * 32 + ps * RPP + prow;
-        const float4 v = *reinterpret_cast<const float4*>(x_b + (long long)min(max(g, 0), p.T - 1) * C + wn * 32 + pc4);
-        rowv[m][ps] = (g >= 0 && g < p.T) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = *reinterpret_cast<const float4*>(x_b + (long long)min(max(g, 0), T - 1) * C + wn * 32 + pc4);
+        rowv[m][ps] = (g >= 0 && g < T) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -699,110 +713,132 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void rb_bf16_kerne
         const float4 v = *reinterpret_cast<const float4*>(patch + li * ELD + 8 * q + 4 * lh);
         xres[m][4 * q + 0] = v.x; xres[m][4 * q + 1] = v.y; xres[m][4 * q + 2] = v.z; xres[m][4 * q + 3] = v.w;
       }
+      if constexpr (STAGE) x0[m] = xres[m];
     }
   }
-  // an accumulator-layout tile -> operand image: (+ bias), lrelu, zero outside [0, T), round to bf16; four consecutive channels of one
-  // position per register quad = 8 bytes of that position's row
-  auto write_image = [&](const f32x16 (&src)[MT], unsigned char* img, const int guard, const float* bias /* [C] or null */) __attribute__((always_inline)) {
-    float4 bq[4];
-    if (bias) {
+  BC_STAMP(d1);
+
+  const int nmem = STAGE ? grp.n : 1;
+  for (int mem = 0; mem < nmem; ++mem) {
+    const RbParams& p = grp.p[STAGE ? mem : member];
+    const int KW = p.KW, hk = (KW - 1) / 2, NP = p.n_pairs;
+    const int NU = NCH * KW;
+    // an accumulator-layout tile -> operand image: (+ bias), lrelu, zero outside [0, T), round to bf16; four consecutive channels of one
+    // position per register quad = 8 bytes of that position's row
+    auto write_image = [&](const f32x16 (&src)[MT], unsigned char* img, const int guard, const float* bias /* [C] or null */) __attribute__((always_inline)) {
+      float4 bq[4];
+      if (bias) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + wn * 32 + 8 * q + 4 * lh);
-    }
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + wn * 32 + 8 * q + 4 * lh);
+      }
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int row = wm * (32 * MT) + m * 32 + li;
-      const int g = origin + row;
-      const bool ok = g >= 0 && g < p.T;
-      unsigned char* dst = img + (row + guard) * RS + wn * 64 + lh * 8;
+      for (int m = 0; m < MT; ++m) {
+        const int row = wm * (32 * MT) + m * 32 + li;
+        const int g = origin + row;
+        const bool ok = g >= 0 && g < T;
+        unsigned char* dst = img + (row + guard) * RS + wn * 64 + lh * 8;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v[4] = {src[m][4 * q], src[m][4 * q + 1], src[m][4 * q + 2], src[m][4 * q + 3]};
-        if (bias) { v[0] += bq[q].x; v[1] += bq[q].y; v[2] += bq[q].z; v[3] += bq[q].w; }
+        for (int q = 0; q < 4; ++q) {
+          float v[4] = {src[m][4 * q], src[m][4 * q + 1], src[m][4 * q + 2], src[m][4 * q + 3]};
+          if (bias) { v[0] += bq[q].x; v[1] += bq[q].y; v[2] += bq[q].z; v[3] += bq[q].w; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = fmaxf(v[i], v[i] * p.slope);
-          v[i] = ok ? v[i] : 0.f;
+          for (int i = 0; i < 4; ++i) {
+            v[i] = fmaxf(v[i], v[i] * p.slope);
+            v[i] = ok ? v[i] : 0.f;
+          }
+          uint2 h;
+          h.x = bc_pack(v[0], v[1]);
+          h.y = bc_pack(v[2], v[3]);
+          *reinterpret_cast<uint2*>(dst + q * 16) = h;
         }
-        uint2 h;
-        h.x = bc_pack(v[0], v[1]);
-        h.y = bc_pack(v[2], v[3]);
-        *reinterpret_cast<uint2*>(dst + q * 16) = h;
+      }
+    };
+    if constexpr (STAGE) {
+      if (mem > 0) {   // the next ResBlock starts from x_0 again; its first convolution's weights
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xres[m] = x0[m];
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[0][0]), 0, NCH * NU * 2048, 0x00020000);
+        E2ETTS_BC_RING_FILL(w_rsrc, nt0, NU)
       }
     }
-  };
-  write_image(xres, Xs, gx, nullptr);
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
-
-  BC_STAMP(d1);
-  for (int pm = 0; pm < NP; ++pm) {
-    const int d = p.dil[pm];
-    __syncthreads();  // X = lrelu(x_pm) visible (and every wavefront is done with I of the previous pair)
-    BC_STAMP(d2);
-    // conv1: position r reads X rows r + gx + (j - hk) d
-    {
-      const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[pm][0]), 0, NCH * NU * 2048, 0x00020000);
-      const unsigned char* a_lane = Xs + (wm * (32 * MT) + li + gx - hk * d) * RS + lh * 16;
-      const int tap_step = d * RS;
-      E2ETTS_BC_KLOOP(w_rsrc, nt0, NU, a_lane, KW, tap_step)
-    }
-    BC_STAMP(d3);
-    sc1 += d3 - d2;
-    const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[pm][1]), 0, NCH * NU * 2048, 0x00020000);
-    E2ETTS_BC_RING_FILL(w2_rsrc, nt0, NU)
-    {
-      f32x16 t[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) t[m] = acc[m][0];
-      write_image(t, Is, hk, p.b1[pm]);   // I = lrelu(c1 + b1), zero outside [0, T)
-    }
+    write_image(xres, Xs, gx, nullptr);   // (X was last read before the previous ResBlock's last barrier)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
-    __syncthreads();  // I visible; every wavefront is done reading X
-    BC_STAMP(d4);
-    se1 += d4 - d3;
-    // conv2: position r reads I rows r + hk + (j - hk) = r + j
-    {
-      const unsigned char* a_lane = Is + (wm * (32 * MT) + li) * RS + lh * 16;
-      const int tap_step = RS;
-      E2ETTS_BC_KLOOP(w2_rsrc, nt0, NU, a_lane, KW, tap_step)
-    }
-    BC_STAMP(d5);
-    sc2 += d5 - d4;
-    if (pm + 1 < NP) {
-      const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[pm + 1][0]), 0, NCH * NU * 2048, 0x00020000);
-      E2ETTS_BC_RING_FILL(w_rsrc, nt0, NU)
-    }
-    // x_{pm+1} = (c2 + b2) + x_pm, in registers
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 bv = *reinterpret_cast<const float4*>(p.b2[pm] + wn * 32 + 8 * q + 4 * lh);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        xres[m][4 * q + 0] = (acc[m][0][4 * q + 0] + bv.x) + xres[m][4 * q + 0];
-        xres[m][4 * q + 1] = (acc[m][0][4 * q + 1] + bv.y) + xres[m][4 * q + 1];
-        xres[m][4 * q + 2] = (acc[m][0][4 * q + 2] + bv.z) + xres[m][4 * q + 2];
-        xres[m][4 * q + 3] = (acc[m][0][4 * q + 3] + bv.w) + xres[m][4 * q + 3];
-        acc[m][0][4 * q + 0] = 0.f; acc[m][0][4 * q + 1] = 0.f; acc[m][0][4 * q + 2] = 0.f; acc[m][0][4 * q + 3] = 0.f;
+
+    for (int pm = 0; pm < NP; ++pm) {
+      const int d = p.dil[pm];
+      __syncthreads();  // X = lrelu(x_pm) visible (and every wavefront is done with I of the previous pair)
+      BC_STAMP(d2);
+      // conv1: position r reads X rows r + gx + (j - hk) d
+      {
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[pm][0]), 0, NCH * NU * 2048, 0x00020000);
+        const unsigned char* a_lane = Xs + (wm * (32 * MT) + li + gx - hk * d) * RS + lh * 16;
+        const int tap_step = d * RS;
+        E2ETTS_BC_KLOOP(w_rsrc, nt0, NU, a_lane, KW, tap_step)
       }
-    }
-    if (pm + 1 < NP) write_image(xres, Xs, gx, nullptr);  // X is dead since the barrier above
+      BC_STAMP(d3);
+      sc1 += d3 - d2;
+      const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[pm][1]), 0, NCH * NU * 2048, 0x00020000);
+      E2ETTS_BC_RING_FILL(w2_rsrc, nt0, NU)
+      {
+        f32x16 t[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) t[m] = acc[m][0];
+        write_image(t, Is, hkI, p.b1[pm]);   // I = lrelu(c1 + b1), zero outside [0, T)
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.f;
+      __syncthreads();  // I visible; every wavefront is done reading X
+      BC_STAMP(d4);
+      se1 += d4 - d3;
+      // conv2: position r reads I rows r + hkI + (j - hk)
+      {
+        const unsigned char* a_lane = Is + (wm * (32 * MT) + li + hkI - hk) * RS + lh * 16;
+        const int tap_step = RS;
+        E2ETTS_BC_KLOOP(w2_rsrc, nt0, NU, a_lane, KW, tap_step)
+      }
+      BC_STAMP(d5);
+      sc2 += d5 - d4;
+      if (pm + 1 < NP) {
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bimg[pm + 1][0]), 0, NCH * NU * 2048, 0x00020000);
+        E2ETTS_BC_RING_FILL(w_rsrc, nt0, NU)
+      }
+      // x_{pm+1} = (c2 + b2) + x_pm, in registers
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.b2[pm] + wn * 32 + 8 * q + 4 * lh);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          xres[m][4 * q + 0] = (acc[m][0][4 * q + 0] + bv.x) + xres[m][4 * q + 0];
+          xres[m][4 * q + 1] = (acc[m][0][4 * q + 1] + bv.y) + xres[m][4 * q + 1];
+          xres[m][4 * q + 2] = (acc[m][0][4 * q + 2] + bv.z) + xres[m][4 * q + 2];
+          xres[m][4 * q + 3] = (acc[m][0][4 * q + 3] + bv.w) + xres[m][4 * q + 3];
+          acc[m][0][4 * q + 0] = 0.f; acc[m][0][4 * q + 1] = 0.f; acc[m][0][4 * q + 2] = 0.f; acc[m][0][4 * q + 3] = 0.f;
+        }
+      }
+      if (pm + 1 < NP) write_image(xres, Xs, gx, nullptr);  // X is dead since the barrier above
 #ifdef E2ETTS_BC_DIAG
-    { unsigned long long dz; BC_STAMP(dz); se2 += dz - d5; }
+      { unsigned long long dz; BC_STAMP(dz); se2 += dz - d5; }
 #endif
+    }
+    if constexpr (STAGE) {   // the running sum over the ResBlocks, in the join's order: (S_0 + S_1) + S_2 ...
+#pragma unroll
+      for (int m = 0; m < MT; ++m) sum[m] = mem == 0 ? xres[m] : sum[m] + xres[m];
+    }
   }
   BC_STAMP(d2);
 
-  // ---- out = x_n (+ out_old, / div) on the positions this tile owns: tile rows [H, R - H), global rows < T.  Through wave-private patches
-  // again (over X, dead since the last conv1), so that the stores are whole row segments.
-  const int g_end = min((tile + 1) * RO, p.T);
+  // ---- out = x_n (+ out_old, / div) -- STAGE: the sum over the ResBlocks / n -- on the positions this tile owns: tile rows [H, R - H),
+  // global rows < T.  Through wave-private patches again (over X, dead since the last conv1), so that the stores are whole row segments.
+  const int g_end = min((tile + 1) * RO, T);
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   {
+    const RbParams& p = grp.p[member];
+    const float sdiv = (float)grp.n;
     float* patch = reinterpret_cast<float*>(Xs) + wave * (32 * ELD);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -811,19 +847,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN) / 4) void rb_bf16_kerne
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
           const int g = origin + wm * (32 * MT) + m * 32 + ps * RPP + prow;
-          ov[ps] = *reinterpret_cast<const f32x4_t*>(out_b + (long long)min(max(g, 0), p.T - 1) * C + wn * 32 + pc4);
+          ov[ps] = *reinterpret_cast<const f32x4_t*>(out_b + (long long)min(max(g, 0), T - 1) * C + wn * 32 + pc4);
         }
       }
+      const f32x16& src = STAGE ? sum[STAGE ? m : 0] : xres[m];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(patch + li * ELD + 8 * q + 4 * lh) = make_float4(xres[m][4 * q], xres[m][4 * q + 1], xres[m][4 * q + 2], xres[m][4 * q + 3]);
+        *reinterpret_cast<float4*>(patch + li * ELD + 8 * q + 4 * lh) = make_float4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
         const int row = wm * (32 * MT) + m * 32 + ps * RPP + prow;
         const int g = origin + row;
         const float4 pv = *reinterpret_cast<const float4*>(patch + (ps * RPP + prow) * ELD + pc4);
         f32x4_t v = {pv.x, pv.y, pv.z, pv.w};
-        if (ACCUM && p.accumulate) {
+        if (STAGE) {
+          if (grp.n > 1) v = v / sdiv;
+        } else if (ACCUM && p.accumulate) {
           v += ov[ps];
           if (p.out_div != 1.0f) v = v / p.out_div;
         }
@@ -1112,12 +1151,42 @@ const char* rb_launch(const RbParams* ps, int n, hipStream_t s) {
   if (nwg >= (1LL << 31)) return "rb_bf16: grid too large";
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_bf16_kernel<MT, WGM, WGN, D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_bf16_kernel<MT, WGM, WGN, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_bf16_kernel<MT, WGM, WGN, D, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_bf16_kernel<MT, WGM, WGN, D, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  if (any_acc) hipLaunchKernelGGL((rb_bf16_kernel<MT, WGM, WGN, D, true>), dim3((unsigned)nwg), dim3(64 * WGM * WGN), lds, s, g);
-  else hipLaunchKernelGGL((rb_bf16_kernel<MT, WGM, WGN, D, false>), dim3((unsigned)nwg), dim3(64 * WGM * WGN), lds, s, g);
+  if (any_acc) hipLaunchKernelGGL((rb_bf16_kernel<MT, WGM, WGN, D, true, false>), dim3((unsigned)nwg), dim3(64 * WGM * WGN), lds, s, g);
+  else hipLaunchKernelGGL((rb_bf16_kernel<MT, WGM, WGN, D, false, false>), dim3((unsigned)nwg), dim3(64 * WGM * WGN), lds, s, g);
+  return hipGetLastError() == hipSuccess ? nullptr : "rb_bf16: launch failed";
+}
+
+// STAGE form: one workgroup per tile computes every member and writes their sum / n to ps[0].out
+template <int MT, int WGM, int WGN, int D>
+const char* rb_launch_stage(const RbParams* ps, int n, hipStream_t s) {
+  constexpr int R = 32 * MT * WGM, RS = WGN * 64 + 16;
+  BRbGroup g;
+  g.n = n;
+  g.st_H = g.st_gx = g.st_hk = 0;
+  for (int k = 0; k < n; ++k) {
+    int H, gx;
+    rb_geometry(ps[k], H, gx);
+    g.st_H = std::max(g.st_H, H); g.st_gx = std::max(g.st_gx, gx); g.st_hk = std::max(g.st_hk, (ps[k].KW - 1) / 2);
+    g.p[k] = ps[k];
+  }
+  const int RO = R - 2 * g.st_H;
+  if (RO < R / 2) return "rb_bf16: receptive field too wide for the tile";
+  const size_t lds = (size_t)((R + 2 * g.st_gx) + (R + 2 * g.st_hk)) * RS + 64;
+  if (lds > 160 * 1024) return "rb_bf16: LDS images exceed the CU's 160 KiB";
+  const int rtiles = (ps[0].T + RO - 1) / RO;
+  const long long nwg = (long long)rtiles * ps[0].B;
+  if (nwg >= (1LL << 31)) return "rb_bf16: grid too large";
+  for (int k = 0; k < BC_GROUP_MAX; ++k) { g.wg_end[k] = (int)nwg; g.rtiles[k] = rtiles; }
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rb_bf16_kernel<MT, WGM, WGN, D, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((rb_bf16_kernel<MT, WGM, WGN, D, false, true>), dim3((unsigned)nwg), dim3(64 * WGM * WGN), lds, s, g);
   return hipGetLastError() == hipSuccess ? nullptr : "rb_bf16: launch failed";
 }
 
@@ -1156,9 +1225,39 @@ const char* launch_rb_bf16_group(const RbParams* ps, int n, hipStream_t s) {
     if (p.B != ps[0].B || p.T != ps[0].T || p.C != ps[0].C) return "rb_bf16: the members of a group share B, T and C";
   }
   // 32 channels: 8 wavefronts of 64 positions each (two per SIMD: one covers the other's image writes and barriers) or 4 of 128
-  static const int w32 = getenv("E2ETTS_BRB_W32") ? atoi(getenv("E2ETTS_BRB_W32")) : 8;   // tuning aid
+  static const int w32 = getenv("E2ETTS_BRB_W32") ? atoi(getenv("E2ETTS_BRB_W32")) : 8;   // tuning aid (3: tiles of 384 positions, two workgroups per CU)
+  if (ps[0].C == 32 && w32 == 3) {
+    for (int k = 0; k < n; ++k) {
+      int H, gx;
+      rb_geometry(ps[k], H, gx);
+      if (384 - 2 * H < 192) return "rb_bf16: receptive field too wide for the 384-position tile";
+    }
+    return rb_launch<3, 4, 1, 6>(ps, n, s);
+  }
   if (ps[0].C == 32) return w32 == 4 ? rb_launch<4, 4, 1, 4>(ps, n, s) : rb_launch<2, 8, 1, 8>(ps, n, s);
   return rb_launch<4, 4, 2, 4>(ps, n, s);
+}
+
+bool rb_bf16_stage_supported(const RbParams* ps, int n) {
+  static const bool on = !(getenv("E2ETTS_BRB_STAGE") && atoi(getenv("E2ETTS_BRB_STAGE")) == 0);   // tuning aid: 0 keeps one workgroup per ResBlock
+  if (!on || !ps || n < 1 || n > BC_GROUP_MAX || ps[0].C != 32) return false;
+  int Hm = 0, gxm = 0, hkm = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!rb_bf16_supported(ps[k]) || ps[k].accumulate || ps[k].x != ps[0].x || ps[k].B != ps[0].B || ps[k].T != ps[0].T || ps[k].C != ps[0].C ||
+        ps[k].slope != ps[0].slope)
+      return false;
+    int H, gx;
+    rb_geometry(ps[k], H, gx);
+    Hm = std::max(Hm, H); gxm = std::max(gxm, gx); hkm = std::max(hkm, (ps[k].KW - 1) / 2);
+  }
+  return 512 - 2 * Hm >= 256 && (size_t)((512 + 2 * gxm) + (512 + 2 * hkm)) * ((ps[0].C / 32) * 64 + 16) + 64 <= 160 * 1024;
+}
+
+const char* launch_rb_bf16_stage(const RbParams* ps, int n, hipStream_t s) {
+  if (!rb_bf16_stage_supported(ps, n)) return "rb_bf16: unsupported stage launch";
+  if (!ps[0].x || !ps[0].out || ps[0].x == ps[0].out) return "rb_bf16: bad pointers";
+  if (((uintptr_t)ps[0].x | (uintptr_t)ps[0].out) & 15) return "rb_bf16: pointers must be 16-byte aligned";
+  return rb_launch_stage<2, 8, 1, 4>(ps, n, s);
 }
 
 size_t bf16_image_bytes(int Cout, int KW, int Cin, int tap_split) {

@@ -1276,6 +1276,7 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     // ---- grouped launches (see group_mode above): pair m of every ResBlock in one launch; at 256 channels, where a pair runs as two
     // convolutions with a bf16 hand-over, conv1 of every ResBlock and then conv2 of every ResBlock
     bool grouped_stage = false;
+    bool joined_in_kernel = false;   // the stage's launch already wrote (S_0 + S_1 + ...) / n to S
     if (group_mode) {
       float* Sj[E2ETTS_MAX_RB_KERNELS]; float* T1j[E2ETTS_MAX_RB_KERNELS]; float* CURj[E2ETTS_MAX_RB_KERNELS];
       int order[E2ETTS_MAX_RB_KERNELS];   // dispatch order inside a launch: largest kernel size first
@@ -1294,7 +1295,24 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
       }
       // 32 / 64 channels: the WHOLE ResBlock of every kernel size in one launch (these stages' tensors, 35 MB per 542-frame window at 48 kHz,
       // stream through the Infinity Cache: pair by pair each is read twice and written once per pair)
-      {
+      if (e->fuse_pairs >= 2) {   // ... and, where one workgroup can hold it (32 channels), ALL the ResBlocks of the stage and their sum
+        RbParams rq[E2ETTS_MAX_RB_KERNELS];
+        bool st_ok = true;
+        double fl = 0;
+        for (int j = 0; j < nk && st_ok; ++j) {   // in j order: the kernel adds the ResBlocks' results as the join does, (S_0 + S_1) + S_2
+          st_ok = rb_params(i, j, co, n, XU, S, rq[j]);
+          if (st_ok) fl += rb_bf16_flops(rq[j]);
+        }
+        if (st_ok && rb_bf16_stage_supported(rq, nk)) {
+          char nm[48];
+          snprintf(nm, sizeof nm, "rb_bf16_stage_%d", co);
+          ProfScope ps(e, nm, fl, 4.0 * 2.0 * B * (double)n * co);
+          KCHK(e, launch_rb_bf16_stage(rq, nk, e->stream));
+          grouped_stage = true;
+          joined_in_kernel = true;
+        }
+      }
+      if (!grouped_stage) {
         RbParams rq[E2ETTS_MAX_RB_KERNELS];
         bool rb_ok = e->fuse_pairs >= 2;
         double fl = 0, by = 0;
@@ -1543,7 +1561,8 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     // its launch and its pass over four tensors (142 MB at the 32- and 64-channel stages of a 542-frame window at 48 kHz).
     bool deferred = false;
     static const bool defer_env = !(getenv("E2ETTS_VOC_DEFER_JOIN") && atoi(getenv("E2ETTS_VOC_DEFER_JOIN")) == 0);   // tuning aid
-    if (conc && grouped_stage && defer_env && nk <= 4) {
+    if (joined_in_kernel) deferred = true;   // nothing left to join
+    if (conc && grouped_stage && !joined_in_kernel && defer_env && nk <= 4) {
       bool can = false;
       if (i + 1 < c.voc_stages) {
         ConvParams q;

@@ -191,6 +191,10 @@ struct RbParams {
 bool rb_bf16_supported(const RbParams& p);
 const char* launch_rb_bf16_group(const RbParams* p, int n, hipStream_t s);   // members share B, T, C, n_pairs; KW / dilations / buffers per member
 inline const char* launch_rb_bf16(const RbParams& p, hipStream_t s) { return launch_rb_bf16_group(&p, 1, s); }
+// ALL the ResBlocks of a stage on the same input (reference V/generator.py:44-48) in one launch, each workgroup computing every member on
+// its tile from ONE load of x and writing out = (((rb_0 + rb_1) + rb_2) ...) / n to p[0].out: no partial sums in memory, no join (32 channels)
+bool rb_bf16_stage_supported(const RbParams* p, int n);
+const char* launch_rb_bf16_stage(const RbParams* p, int n, hipStream_t s);
 double rb_bf16_flops(const RbParams& p);
 double rb_bf16_bytes(const RbParams& p);
 const char* launch_resblock_pair(const PairParams& p, hipStream_t s);

@@ -587,6 +587,8 @@ def main():
         "tiny_lpad_b3": lambda: case_model(models, "tiny_lpad_b3", pv_variant(cfgmod.tiny_config(), "lpad"), "varied", [17, 28, 5], 2, (1.0, 1.0, 1.0), 1500, 2e-3, "full"),
         "tiny_frame_b3": lambda: case_model(models, "tiny_frame_b3", pv_variant(cfgmod.tiny_config(), "frame"), "varied", [14, 22, 6], 1, (1.0, 1.0, 1.0), 1600, 1e-3, "full", max_tries=80),
         "tiny_pframe_b3": lambda: case_model(models, "tiny_pframe_b3", pv_variant(cfgmod.tiny_config(), "pframe"), "varied", [14, 22, 6], 0, (1.0, 1.05, 0.95), 1700, 1e-3, "full", max_tries=80),
+        # the frame-level features at FULL dimensions (384 hidden, 256-channel predictors over T rows)
+        "full_frame_b2": lambda: case_model(models, "full_frame_b2", pv_variant(cfgmod.default_config(), "frame"), "varied", [40, 27], 1, (1.0, 1.0, 1.0), 1800, 1e-3, "medium", max_tries=80),
         "c1_plumbing": lambda: case_model(models, "c1_plumbing", full, "varied", [40], 1, (1.0, 1.0, 1.0), 1, 1e-3, "medium"),
         "full_b3": lambda: case_model(models, "full_b3", full, "varied", [48, 31, 20], 1, (1.0, 1.0, 1.0), 500, 1e-3, "medium"),
     }

@@ -86,7 +86,7 @@ def test_tiny_model_full_trace(name):
         assert close.mean() >= 0.999, prec
 
 
-@pytest.mark.parametrize("name", ["c1_plumbing", "full_b3", "c2_latency", "full_cf_b2"])
+@pytest.mark.parametrize("name", ["c1_plumbing", "full_b3", "c2_latency", "full_cf_b2", "full_frame_b2"])
 def test_default_model(name):
     g = load_golden(name)
     cfg, eng = engine_for(g, name)
@@ -1077,6 +1077,47 @@ def test_random_model_geometries_match_the_oracle(seed):
             assert T == T2 and np.array_equal(ml, ml2) and np.array_equal(ml, omel_lens)
             for b, n in enumerate(ml * hop):
                 np.testing.assert_array_equal(rag[b, :n], full[b, :n])
+    finally:
+        eng.close()
+
+
+def test_frame_level_features_up_to_the_last_row_of_the_position_table():
+    """VERDICT r3 item 8 / commit 71c90f4: with frame_level features the variance predictors' fairseq position table (U/sublayers.py:28-60,
+    which the reference grows on demand) is indexed by FRAME, so it must reach as far as the decoder's own table lets T go (pos_table_rows =
+    4 096): one utterance of 682 phonemes x exactly 6 frames = 4 092 frames runs and matches the numpy oracle (discrete outputs exact, frame
+    level taps included); 683 phonemes = 4 098 frames is refused with E2ETTS_EINVAL and a message naming the table, not computed past it."""
+    from e2e_tts_amd import synth_weights as sw
+    from e2e_tts_amd.packer import variance_position_table
+    from e2e_tts_amd.runtime import engine_from_states
+    from oracle import ref_numpy as orc
+    from oracle.make_goldens import pv_variant
+    cfg = pv_variant(cfgmod.tiny_config(), "frame")
+    stats = cfgmod.DEFAULT_STATS
+    ac = sw.make_acoustic_state(cfg, stats, 4, seed=77, mode="fixed", frames_per_phoneme=6)
+    voc = sw.make_vocoder_state(cfg, seed=78)
+    eng = engine_from_states(cfg, stats, ac, voc, device=0)
+    try:
+        rng = np.random.Generator(np.random.PCG64(79))
+        spk = np.array([1], np.int64)
+        L = 682
+        ids = rng.integers(4, 131, size=(1, L)).astype(np.int64)
+        lens = np.array([L], np.int64)
+        eng.set_precision("fp32")
+        r = eng.acoustic(ids, lens, spk, want=("dur", "mel_lens", "pitch_idx", "energy_idx"))
+        assert r["T"] == 6 * L == 4092 and r["pitch_idx"].shape == (1, 4092) and r["energy_idx"].shape == (1, 4092)
+        mel, mel_post = eng.fetch_mel(1, r["T"])
+        H = cfg["models"]["fastspeech2"]["encoder_hidden"]
+        o = orc.AcousticOracle(ac, cfg, stats, var_pos_table=variance_position_table(4098, H))
+        (omel, omel_post, odur), omel_lens = o.inference(spk, ids, lens)
+        np.testing.assert_array_equal(r["dur"], odur)
+        np.testing.assert_array_equal(r["mel_lens"], omel_lens)
+        np.testing.assert_array_equal(r["pitch_idx"], o.trace["pitch_idx"])
+        np.testing.assert_array_equal(r["energy_idx"], o.trace["energy_idx"])
+        assert mean_l1(mel_post, omel_post) < MEL_L1
+        L2 = 683
+        ids2 = rng.integers(4, 131, size=(1, L2)).astype(np.int64)
+        with pytest.raises(ValueError, match="position table"):
+            eng.acoustic(ids2, np.array([L2], np.int64), spk, want=("mel_lens",))
     finally:
         eng.close()
 

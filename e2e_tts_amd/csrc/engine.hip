@@ -1416,7 +1416,29 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     // launches of ~15 us per ResBlock) the host needs longer to enqueue a ResBlock's launches than the GPU to run them, so the stream
     // enqueued last starts late by the others' enqueue time -- and the last ResBlock has the largest kernel size, the stage's critical
     // path.  Which stream a ResBlock runs on, and every result bit, are unchanged.
-    for (int jj = 0; jj < c.voc_n_kernels && !grouped_stage; ++jj) {
+    // Large grids, plain bf16, padded batch: the stage form of rb_bf16 (every ResBlock of the stage and their sum per workgroup: x read once,
+    // the sum written once) where it exists (32 channels) -- there these stages run on the HBM roofline as pair launches.
+    bool whole_stage = false;
+    {
+      static const int stage_env = getenv("E2ETTS_BRB_STAGE_BIG") ? atoi(getenv("E2ETTS_BRB_STAGE_BIG")) : 1;   // tuning aid
+      if (stage_env && !grouped_stage && !conc && e->fuse_pairs >= 2 && !act_stage[i + 1] && nk <= BC_GROUP_MAX) {
+        RbParams rq[E2ETTS_MAX_RB_KERNELS];
+        bool st_ok = true;
+        double fl = 0;
+        for (int j = 0; j < nk && st_ok; ++j) {
+          st_ok = rb_params(i, j, co, n, XU, S, rq[j]);
+          if (st_ok) fl += rb_bf16_flops(rq[j]);
+        }
+        if (st_ok && rb_bf16_stage_supported(rq, nk)) {
+          char nm[48];
+          snprintf(nm, sizeof nm, "rb_bf16_stage_%d", co);
+          ProfScope ps(e, nm, fl, 4.0 * 2.0 * B * (double)n * co);
+          KCHK(e, launch_rb_bf16_stage(rq, nk, e->stream));
+          whole_stage = true;
+        }
+      }
+    }
+    for (int jj = 0; jj < c.voc_n_kernels && !grouped_stage && !whole_stage; ++jj) {
       const int j = conc ? c.voc_n_kernels - 1 - jj : jj;
       const int idx = i * c.voc_n_kernels + j;
       const int k = c.voc_rb_kernel[j];
@@ -1495,7 +1517,10 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
             auto i1 = e->bimg_of.find(e->rb_c1[idx][m].wx3), i2 = e->bimg_of.find(e->rb_c2[idx][m].wx3);
             if (i1 != e->bimg_of.end() && i2 != e->bimg_of.end()) { q.bimg1 = i1->second.first; q.bimg2 = i2->second.first; }
           }
-          const bool bpair = pair_bf16_supported(q);
+          // (at large grids the two kernel families are level pair by pair; the whole 60 s utterance in one call: 7.69 ms with pair_bf16
+          // everywhere against 7.91 with resblock_pair.hip there, same box; E2ETTS_BPAIR_BIG=0 keeps the latter -- same bits)
+          static const bool bpair_big = !(getenv("E2ETTS_BPAIR_BIG") && atoi(getenv("E2ETTS_BPAIR_BIG")) == 0);
+          const bool bpair = (bpair_big || small_window) && pair_bf16_supported(q);
           if (bpair && !fine) snprintf(nm, sizeof nm, "pair_bf16_%d", co);
           ProfScope ps(e, nm, resblock_pair_flops(q), resblock_pair_bytes(q));
           KCHK(e, bpair ? launch_pair_bf16(q, e->stream) : launch_resblock_pair(q, e->stream));

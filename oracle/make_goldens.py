@@ -586,6 +586,10 @@ def main():
         "tiny_plog_b3": lambda: case_model(models, "tiny_plog_b3", pv_variant(cfgmod.tiny_config(), "plog"), "varied", [19, 26, 8], 3, (1.0, 1.0, 1.0), 1400, 2e-3, "full"),
         "tiny_lpad_b3": lambda: case_model(models, "tiny_lpad_b3", pv_variant(cfgmod.tiny_config(), "lpad"), "varied", [17, 28, 5], 2, (1.0, 1.0, 1.0), 1500, 2e-3, "full"),
         "tiny_frame_b3": lambda: case_model(models, "tiny_frame_b3", pv_variant(cfgmod.tiny_config(), "frame"), "varied", [14, 22, 6], 1, (1.0, 1.0, 1.0), 1600, 1e-3, "full", max_tries=80),
+        # energy alone at the frame level (pitch stays on the phonemes), and frame-level features under Conformer blocks (whose
+        # unmasked attention reads the embeddings added on padded rows)
+        "tiny_eframe_b3": lambda: case_model(models, "tiny_eframe_b3", pv_variant(cfgmod.tiny_config(), "eframe"), "varied", [14, 22, 6], 2, (1.0, 0.95, 1.05), 1900, 1e-3, "full", max_tries=80),
+        "tiny_cf_frame_b3": lambda: case_model(models, "tiny_cf_frame_b3", pv_variant(cf_tiny(), "frame"), "varied", [14, 22, 6], 1, (1.0, 1.0, 1.0), 2000, 1e-3, "full", max_tries=80),
         "tiny_pframe_b3": lambda: case_model(models, "tiny_pframe_b3", pv_variant(cfgmod.tiny_config(), "pframe"), "varied", [14, 22, 6], 0, (1.0, 1.05, 0.95), 1700, 1e-3, "full", max_tries=80),
         # the frame-level features at FULL dimensions (384 hidden, 256-channel predictors over T rows)
         "full_frame_b2": lambda: case_model(models, "full_frame_b2", pv_variant(cfgmod.default_config(), "frame"), "varied", [40, 27], 1, (1.0, 1.0, 1.0), 1800, 1e-3, "medium", max_tries=80),
@@ -606,6 +610,12 @@ def main():
         if args.only and name != args.only:
             continue
         fn()
+
+
+def cf_tiny():
+    cfg = cfgmod.tiny_config()
+    cfg["models"]["fastspeech2"]["building_block"]["block_type"] = "conformer"
+    return cfg
 
 
 def hv_variant(cfg):
@@ -631,6 +641,8 @@ def pv_variant(cfg, which):
         cfg["models"]["fastspeech2"]["variance"]["variance_predictor"]["ffn_padding"] = "LEFT"
     elif which == "frame":  # both features at the frame level (U/layers.py:249-257)
         ve["pitch_feature"] = ve["energy_feature"] = "frame_level"
+    elif which == "eframe":  # energy at the frame level, pitch on the phonemes
+        ve["energy_feature"] = "frame_level"
     else:                   # "pframe": pitch at the frame level, energy on the phonemes
         ve["pitch_feature"] = "frame_level"
     return cfg

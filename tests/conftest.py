@@ -41,7 +41,7 @@ def config_for(name):
     if "_hv_" in name:  # decoder_head != encoder_head, energy predictor of its own depth / kernel (oracle/make_goldens.py: hv_variant)
         from oracle.make_goldens import hv_variant
         cfg = hv_variant(cfg)
-    for tag in ("nouv", "plog", "lpad", "frame", "pframe"):  # use_uv False / pitch_quantization "log" / ffn_padding "LEFT" / frame_level features (oracle/make_goldens.py: pv_variant)
+    for tag in ("nouv", "plog", "lpad", "frame", "pframe", "eframe"):  # use_uv False / pitch_quantization "log" / ffn_padding "LEFT" / frame_level features (oracle/make_goldens.py: pv_variant)
         if f"_{tag}_" in name:
             from oracle.make_goldens import pv_variant
             cfg = pv_variant(cfg, tag)
@@ -55,7 +55,7 @@ def states_for(g, name):
     """Regenerate the synthetic state dicts a fixture was made with (seeds + mode are stored in it)."""
     from e2e_tts_amd import config as cfgmod, synth_weights as sw
     cfg = config_for(name)
-    key = (name.startswith("tiny"), "_cf_" in name, "_hv_" in name, "_nouv_" in name, "_plog_" in name, "_lpad_" in name, "_frame_" in name, "_pframe_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
+    key = (name.startswith("tiny"), "_cf_" in name, "_hv_" in name, "_nouv_" in name, "_plog_" in name, "_lpad_" in name, "_frame_" in name, "_pframe_" in name, "_eframe_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
     if key not in _STATE_CACHE:
         ac = sw.make_acoustic_state(cfg, cfgmod.DEFAULT_STATS, 4, seed=int(g["weight_seeds"][0]), mode=str(g["mode"]))
         voc = sw.make_vocoder_state(cfg, seed=int(g["weight_seeds"][1]))

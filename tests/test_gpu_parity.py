@@ -22,7 +22,7 @@ _ENGINES = {}
 def engine_for(g, name):
     from e2e_tts_amd.runtime import engine_from_states
     cfg, ac, voc = states_for(g, name)
-    key = (name.startswith("tiny"), "_cf_" in name, "_hv_" in name, "_nouv_" in name, "_plog_" in name, "_lpad_" in name, "_frame_" in name, "_pframe_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
+    key = (name.startswith("tiny"), "_cf_" in name, "_hv_" in name, "_nouv_" in name, "_plog_" in name, "_lpad_" in name, "_frame_" in name, "_pframe_" in name, "_eframe_" in name, str(g["mode"]), tuple(int(x) for x in g["weight_seeds"]))
     if key not in _ENGINES:
         _ENGINES[key] = engine_from_states(cfg, cfgmod.DEFAULT_STATS, ac, voc, device=0)
     return cfg, _ENGINES[key]
@@ -52,7 +52,7 @@ def check_discrete(r, g):
 # *_cf_*: the same model with Conformer blocks (building_block.block_type = "conformer", reference U/blocks/conformer.py);
 # tiny_cf_long runs past max_seq_len in the encoder and the decoder (regenerated position tables in every attention module)
 @pytest.mark.parametrize("name", ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1", "tiny_cf_b3", "tiny_cf_long", "tiny_hv_b3", "tiny_cf_hv_b3",
-                                  "tiny_nouv_b3", "tiny_plog_b3", "tiny_lpad_b3", "tiny_frame_b3", "tiny_pframe_b3"])
+                                  "tiny_nouv_b3", "tiny_plog_b3", "tiny_lpad_b3", "tiny_frame_b3", "tiny_pframe_b3", "tiny_eframe_b3", "tiny_cf_frame_b3"])
 def test_tiny_model_full_trace(name):
     g = load_golden(name)
     cfg, eng = engine_for(g, name)

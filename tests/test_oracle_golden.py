@@ -16,6 +16,7 @@ MODEL_CASES = ["tiny_b3", "tiny_long", "tiny_ctl", "tiny_b1", "c1_plumbing", "fu
                "tiny_hv_b3", "tiny_cf_hv_b3",               # *_hv_*: decoder_head != encoder_head, energy predictor of its own depth / kernel
                "tiny_nouv_b3", "tiny_plog_b3", "tiny_lpad_b3",  # use_uv False / pitch_quantization "log" (U/layers.py:136-160) / ffn_padding "LEFT"
                "tiny_frame_b3", "tiny_pframe_b3",               # pitch + energy / pitch alone at the frame level (U/layers.py:249-257)
+               "tiny_eframe_b3", "tiny_cf_frame_b3",            # energy alone at the frame level; both under Conformer blocks
                "full_frame_b2"]                                 # ... both at the frame level at full dimensions
 
 

@@ -43,9 +43,9 @@ def kernel_class(name: str):
     m = re.search(r"pair_bf16_kernel<\d+, \d+, (\d+)", name)
     if m:
         return f"pair_bf16_group_{32 * int(m.group(1))}"
-    m = re.search(r"rb_bf16_kernel<\d+, \d+, (\d+)", name)
-    if m:
-        return f"rb_bf16_group_{32 * int(m.group(1))}"
+    m = re.search(r"rb_bf16_kernel<\d+, \d+, (\d+), \d+, (?:true|false|0|1), (true|false|0|1)", name)
+    if m:   # the last template argument: the stage form (every ResBlock of the stage per workgroup)
+        return ("rb_bf16_stage_" if m.group(2) in ("true", "1") else "rb_bf16_group_") + str(32 * int(m.group(1)))
     m = re.search(r"conv_rows_kernel<\d+, (\d+), \d+, (true|false|1|0)", name)
     if m:  # SPLITK: the phoneme-level K-split form; otherwise the few-rows form of conv_gemm's arithmetic
         if m.group(2) in ("true", "1"):

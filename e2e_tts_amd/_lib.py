@@ -2,6 +2,7 @@
 library is missing or no GPU is visible, construction raises."""
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import functools
 import threading
@@ -429,25 +430,37 @@ class Engine:
         with self.lock:
             halo = self._check(self.lib.e2etts_vocoder_stream_begin(self._h, B), "e2etts_vocoder_stream_begin")
         self.stream_halo = halo
+        hop = self.dims.hop_length
+
+        def fetch(n_emit):   # the OLDEST unfetched chunk (the engine keeps at most two in flight)
+            out = np.empty((B, n_emit * hop), np.int16 if want_pcm else np.float32)
+            self._check(self.lib.e2etts_vocoder_stream_fetch(self._h, None if want_pcm else _addr(out), _addr(out) if want_pcm else None,
+                                                             out.size), "e2etts_vocoder_stream_fetch")
+            return out
+
         chunks = iter(chunks)
         cur = next(chunks, None)
+        pend = collections.deque()   # (frames made final, the chunk: device memory must outlive the copy the push enqueued)
         while cur is not None:
             nxt = next(chunks, None)
-            n = int(cur.shape[1])
             n_emit = C.c_int(0)
             out = None
-            with self.lock:  # push + fetch of what it made final are one step (the lock is NOT held across the yield below); the
-                # stream's carried context lives in buffers of its own, so one-shot calls may run between steps
-                self._check(self.lib.e2etts_vocoder_stream_push(self._h, _addr(cur), n, 1 if nxt is None else 0, C.byref(n_emit)),
-                            "e2etts_vocoder_stream_push")
+            with self.lock:  # one step: push chunk i (returns once enqueued), then take chunk i - 1's samples while i computes.  The
+                # lock is NOT held across the yield below; the stream's context and its two output slots live in buffers of their own,
+                # so one-shot calls may run between steps
+                self._check(self.lib.e2etts_vocoder_stream_push(self._h, _addr(cur), int(cur.shape[1]), 1 if nxt is None else 0,
+                                                                C.byref(n_emit)), "e2etts_vocoder_stream_push")
                 if n_emit.value > 0:
-                    ns = n_emit.value * self.dims.hop_length
-                    out = np.empty((B, ns), np.int16 if want_pcm else np.float32)
-                    self._check(self.lib.e2etts_vocoder_stream_fetch(self._h, None if want_pcm else _addr(out),
-                                                                     _addr(out) if want_pcm else None, out.size), "e2etts_vocoder_stream_fetch")
+                    pend.append((n_emit.value, cur))
+                if len(pend) == 2:
+                    out = fetch(pend.popleft()[0])
             if out is not None:
                 yield out
             cur = nxt
+        while pend:
+            with self.lock:
+                out = fetch(pend.popleft()[0])
+            yield out
 
     # ---- profiling
     @_locked

@@ -132,9 +132,31 @@ struct e2etts_engine {
   int voc_precision = 0;  // 0: fp32 MFMA (default: the reference's arithmetic), 1: bf16x3 split-precision MFMA, 2: plain bf16 (E2ETTS_PRECISION_*)
   // streaming vocoder (e2etts_vocoder_stream_*): trailing mel frames kept as context / not yet emitted
   DevBuf st_carry, st_win;
-  int st_B = 0, st_carry_n = 0, st_halo = 0, st_emit_n = 0, st_emit_off = 0, st_win_n = 0;
+  int st_B = 0, st_carry_n = 0, st_halo = 0;
   long long st_emitted = 0;
   bool st_open = false, st_done = false;
+  // Two chunks may be in flight: _push enqueues and returns, _fetch takes the OLDEST unfetched chunk.  A chunk's pass depends on the mel
+  // stream only (the carried context is mel frames), so the two passes are independent: each slot has a compute stream, a workspace and
+  // output buffers of its own, and the kernels of chunk i + 1 fill the CUs that chunk i's launch tails and small launches leave idle.
+  // Window assembly, uploads and downloads run on the engine's own stream, which carries no kernels while a stream is open (and is the
+  // one e2etts_order_after orders behind the caller's work).  That makes three streams busy at a time: a process has FOUR hardware
+  // queues by default (GPU_MAX_HW_QUEUES), the null stream holds one, and streams beyond that share a queue, i.e. run in turn --
+  // measured: with a copy stream of its own the two passes landed on one queue and did not overlap at all.
+  struct VocCtx {   // what one vocoder pass works in besides the weights: swapped into the engine around vocoder_impl
+    hipStream_t stream = nullptr;
+    DevBuf v0, v1, v2, v3, vside[E2ETTS_MAX_RB_KERNELS - 1][3];
+    hipStream_t side[E2ETTS_MAX_RB_KERNELS - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[E2ETTS_MAX_RB_KERNELS - 1] = {};
+  };
+  struct StSlot {
+    VocCtx ctx;
+    DevBuf wav, pcm, win;
+    void* pin = nullptr;
+    size_t pin_cap = 0;
+    hipEvent_t done = nullptr, win_ready = nullptr;
+    int emit_n = 0, emit_off = 0, win_n = 0;
+  } st_slot[2];
+  int st_head = 0, st_pending = 0;
   int ragged = 1;         // synthesize(): skip rows of shorter utterances that no valid output sample depends on
   bool rag_short = false; // the last acoustic pass had an utterance shorter than T (else ragged mode has nothing to skip)
   DevBuf actbuf;          // [5 + voc_stages][B] int32 row limits: decoder, mel_linear / postnet, vocoder stage 0 .. voc_stages, encoder (unused on the
@@ -1117,7 +1139,11 @@ int acoustic_impl(e2etts_engine* e, const int64_t* ids, const int64_t* lens, int
 
 // HifiGan.forward (V/generator.py:37-53) on channels-last mel [B, T, n_mel] already in HBM
 int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want_wav, bool want_pcm, const int32_t* ragged_lens = nullptr,
-                 const int64_t* ragged_lens_host = nullptr) {
+                 const int64_t* ragged_lens_host = nullptr, DevBuf* out_wav = nullptr, DevBuf* out_pcm = nullptr) {
+  // out_wav / out_pcm: the streaming path's slot buffers; the resident one-shot result (e->wav, e->pcm, have_wav) is then left alone
+  const bool own_out = out_wav != nullptr;
+  DevBuf& WAV = own_out ? *out_wav : e->wav;
+  DevBuf& PCM = own_out ? *out_pcm : e->pcm;
   const auto& c = e->cfg;
   if (!e->voc_loaded) return e->fail(E2ETTS_ESTATE, "vocoder weights not loaded");
   if (B <= 0 || T <= 0) return e->fail(E2ETTS_EINVAL, "B and T must be positive");
@@ -1139,9 +1165,9 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   RET(ensure(e, e->v1, vb));
   RET(ensure(e, e->v2, vb));
   RET(ensure(e, e->v3, vb));
-  RET(ensure(e, e->wav, (size_t)B * nsamp * 4));
-  RET(ensure(e, e->pcm, (size_t)B * nsamp * 2));
-  e->have_wav = false;
+  RET(ensure(e, WAV, (size_t)B * nsamp * 4));
+  RET(ensure(e, PCM, (size_t)B * nsamp * 2));
+  if (!own_out) e->have_wav = false;
   float *S = ptr<float>(e->v0), *XU = ptr<float>(e->v1), *T1 = ptr<float>(e->v2), *CUR = ptr<float>(e->v3);
 
   // weight selection: split-precision image when requested and present, else fp32
@@ -1221,7 +1247,11 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
   static const bool group_env = !(getenv("E2ETTS_VOC_GROUP") && atoi(getenv("E2ETTS_VOC_GROUP")) == 0);
   const bool small_window = nk > 1 && nk <= E2ETTS_MAX_RB_KERNELS && nk <= BC_GROUP_MAX && (long long)B * T <= conc_frames;
   const bool group_mode = group_env && small_window && e->voc_precision == E2ETTS_PRECISION_BF16 && !ragged_lens && c.voc_resblock == 1 && e->fuse_pairs;
-  const bool conc = (!full_profile || group_mode) && nk > 1 && nk <= E2ETTS_MAX_RB_KERNELS && (long long)B * T <= conc_frames;
+  // A pass in a stream slot (e2etts_vocoder_stream_push) overlaps with the other slot's pass instead: side streams of its own would only
+  // crowd the process's four hardware queues (E2ETTS_STREAM_SIDE=1, tuning aid, keeps them).
+  static const bool side_in_slot = getenv("E2ETTS_STREAM_SIDE") && atoi(getenv("E2ETTS_STREAM_SIDE")) != 0;
+  const bool conc = (!full_profile || group_mode) && nk > 1 && nk <= E2ETTS_MAX_RB_KERNELS && (long long)B * T <= conc_frames &&
+                    (!own_out || side_in_slot || group_mode);
   if (conc) {
     for (int j = 0; j + 1 < nk; ++j) {
       if (!e->side[j]) HIPCHK(e, hipStreamCreateWithFlags(&e->side[j], hipStreamNonBlocking));
@@ -1633,19 +1663,21 @@ int vocoder_impl(e2etts_engine* e, const float* mel_btc, int B, int T, bool want
     RET(conv(e, p));
     {
       ProfScope ps(e, "istft", 0, (double)B * F * pc * 4.0 + (double)B * nsamp * 6.0);
-      KCHK(e, launch_istft(ptr<float>(e->istft_q), pc, ptr<float>(e->istft_sp), ptr<float>(e->istft_ri), ptr<float>(e->wav),
-                           ptr<int16_t>(e->pcm), B, F, c.voc_istft_nfft, c.voc_istft_hop, e->stream));
+      KCHK(e, launch_istft(ptr<float>(e->istft_q), pc, ptr<float>(e->istft_sp), ptr<float>(e->istft_ri), ptr<float>(WAV),
+                           ptr<int16_t>(PCM), B, F, c.voc_istft_nfft, c.voc_istft_hop, e->stream));
     }
     e->istft_B = B;
     e->istft_F = F;
   } else {
     ProfScope ps(e, "conv_post", 2.0 * B * (double)n * 7 * ch, (double)B * n * (ch * 4.0 + 6.0));
-    KCHK(e, launch_conv_post(S, e->voc_post.w, e->voc_post.b, ptr<float>(e->wav), ptr<int16_t>(e->pcm), B, n, (int)ch, 7, e->stream,
+    KCHK(e, launch_conv_post(S, e->voc_post.w, e->voc_post.b, ptr<float>(WAV), ptr<int16_t>(PCM), B, n, (int)ch, 7, e->stream,
                              act_stage[c.voc_stages], act_stage_h[c.voc_stages], pend_add[0] ? pend_add : nullptr, pend_div));
   }
   (void)want_wav; (void)want_pcm;
-  e->voc_B = B; e->voc_T = T;
-  e->have_wav = true;
+  if (!own_out) {
+    e->voc_B = B; e->voc_T = T;
+    e->have_wav = true;
+  }
   return E2ETTS_OK;
 }
 
@@ -1708,12 +1740,25 @@ void e2etts_destroy(e2etts_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
+  for (auto& sl : e->st_slot)
+    if (sl.ctx.stream) (void)hipStreamSynchronize(sl.ctx.stream);
   for (DevBuf* b : e->owned)  // registered by ensure(): no hand-kept list to fall behind when a buffer is added
     if (b->p) (void)hipFree(b->p);
   for (auto& r : e->prof_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
   free_frags(e);
   if (e->h_mel) (void)hipHostFree(e->h_mel);
+  for (auto& sl : e->st_slot) {
+    if (sl.pin) (void)hipHostFree(sl.pin);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.win_ready) (void)hipEventDestroy(sl.win_ready);
+    for (auto& st : sl.ctx.side)
+      if (st) (void)hipStreamDestroy(st);
+    if (sl.ctx.ev_fork) (void)hipEventDestroy(sl.ctx.ev_fork);
+    for (auto& ev : sl.ctx.ev_join)
+      if (ev) (void)hipEventDestroy(ev);
+    if (sl.ctx.stream) (void)hipStreamDestroy(sl.ctx.stream);
+  }
   for (auto& st : e->side)
     if (st) (void)hipStreamDestroy(st);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -2000,19 +2045,65 @@ int e2etts_fetch_wav(e2etts_engine* e, float* wav_out, size_t capacity) {
   return E2ETTS_OK;
 }
 
+// The engine works in ctx (stream, activations, side streams) while this object lives.
+struct CtxSwap {
+  e2etts_engine* e; e2etts_engine::VocCtx& c;
+  void swap() {
+    std::swap(e->stream, c.stream);
+    std::swap(e->v0, c.v0); std::swap(e->v1, c.v1); std::swap(e->v2, c.v2); std::swap(e->v3, c.v3);
+    for (int j = 0; j < E2ETTS_MAX_RB_KERNELS - 1; ++j) {
+      for (int k = 0; k < 3; ++k) std::swap(e->vside[j][k], c.vside[j][k]);
+      std::swap(e->side[j], c.side[j]);
+      std::swap(e->ev_join[j], c.ev_join[j]);
+    }
+    std::swap(e->ev_fork, c.ev_fork);
+  }
+  CtxSwap(e2etts_engine* e_, e2etts_engine::VocCtx& c_) : e(e_), c(c_) { swap(); }
+  ~CtxSwap() { swap(); }
+};
+
 int e2etts_vocoder_stream_begin(e2etts_engine* e, int B) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
+  HIPCHK(e, hipSetDevice(e->device));
   if (!e->voc_loaded) return e->fail(E2ETTS_ESTATE, "vocoder weights not loaded");
   if (B <= 0 || B > 4096) return e->fail(E2ETTS_EINVAL, "B out of range");
+  for (auto& sl : e->st_slot) {
+    if (!sl.done) HIPCHK(e, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (!sl.win_ready) HIPCHK(e, hipEventCreateWithFlags(&sl.win_ready, hipEventDisableTiming));
+    if (!sl.ctx.stream) {
+      HIPCHK(e, hipStreamCreateWithFlags(&sl.ctx.stream, hipStreamNonBlocking));
+      // a slot's workspace is grown by ensure() while it is swapped into the engine, i.e. under the engine members' addresses: the
+      // slot's own DevBufs are what e2etts_destroy must free
+      DevBuf* mine[] = {&sl.ctx.v0, &sl.ctx.v1, &sl.ctx.v2, &sl.ctx.v3};
+      for (DevBuf* b : mine) e->owned.push_back(b);
+      for (auto& row : sl.ctx.vside)
+        for (auto& b : row) e->owned.push_back(&b);
+    }
+    // chunks of an abandoned stream may still be in flight: nothing of theirs is delivered
+    HIPCHK(e, hipStreamSynchronize(sl.ctx.stream));
+  }
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->st_head = 0;
+  e->st_pending = 0;
   e->st_B = B;
   e->st_carry_n = 0;
   e->st_emitted = 0;
-  e->st_emit_n = 0;
   e->st_halo = vocoder_halo_frames(e->cfg);
   e->st_open = true;
   e->st_done = false;
   return e->st_halo;
+}
+
+// Whether a caller's pointer is ordinary (pageable) host memory: such a chunk is copied into the slot's pinned buffer before _push
+// returns, so the caller may reuse it at once; device memory and memory the caller pinned is read by the copy engine later.
+static bool st_pageable_host(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;
+  }
+  return a.type == hipMemoryTypeUnregistered;
 }
 
 int e2etts_vocoder_stream_push(e2etts_engine* e, const float* mel_btc, int n, int last, int* n_frames_out) {
@@ -2021,40 +2112,64 @@ int e2etts_vocoder_stream_push(e2etts_engine* e, const float* mel_btc, int n, in
   HIPCHK(e, hipSetDevice(e->device));
   if (!e->st_open || e->st_done) return e->fail(E2ETTS_ESTATE, "no open vocoder stream");
   if (n < 0 || (n > 0 && !mel_btc)) return e->fail(E2ETTS_EINVAL, "bad chunk");
+  if (e->st_pending >= 2) return e->fail(E2ETTS_ESTATE, "two chunks await e2etts_vocoder_stream_fetch");
   const int B = e->st_B, H = e->st_halo, M = e->cfg.n_mel;
   const int total = e->st_carry_n + n;
   if (n_frames_out) *n_frames_out = 0;
-  e->st_emit_n = 0;
+  auto& sl = e->st_slot[(e->st_head + e->st_pending) & 1];   // free: whatever used it last has been fetched, hence has finished
+  hipStream_t const cp = e->stream;   // assembly and copies: see the note at st_slot
   // window = [carry | new]; carry = up to H already-emitted frames (left context) followed by the frames not yet emitted
   const int left_ctx = (int)std::min<long long>(H, std::min<long long>(e->st_emitted, e->st_carry_n));
   const int emit_end = last ? total : total - H;   // frames before emit_end have their full right context in the window
-  RET(ensure(e, e->st_win, (size_t)B * std::max(total, 1) * M * 4));
+  RET(ensure(e, sl.win, (size_t)B * std::max(total, 1) * M * 4));
   const size_t row_new = (size_t)n * M * 4, row_carry = (size_t)e->st_carry_n * M * 4, row_win = (size_t)total * M * 4;
-  if (e->st_carry_n)
-    HIPCHK(e, hipMemcpy2DAsync(e->st_win.p, row_win, e->st_carry.p, row_carry, row_carry, B, hipMemcpyDeviceToDevice, e->stream));
-  if (n)
-    HIPCHK(e, hipMemcpy2DAsync((char*)e->st_win.p + row_carry, row_win, mel_btc, row_new, row_new, B, hipMemcpyDefault, e->stream));
-  int n_emit = emit_end - left_ctx;
-  if (n_emit > 0) {
-    RET(vocoder_impl(e, ptr<float>(e->st_win), B, total, true, true));
-    e->st_win_n = total;
-    e->st_emit_off = left_ctx;
-    e->st_emit_n = n_emit;
-    e->st_emitted += n_emit;
-  } else {
-    n_emit = 0;
+  const void* src = mel_btc;
+  if (n && st_pageable_host(mel_btc)) {   // taken now, so that the caller may reuse the chunk; sent up by the copy engine
+    const size_t bytes = (size_t)B * row_new;
+    if (sl.pin_cap < bytes) {
+      if (sl.pin) HIPCHK(e, hipHostFree(sl.pin));
+      sl.pin = nullptr;
+      sl.pin_cap = 0;
+      HIPCHK(e, hipHostMalloc(&sl.pin, bytes + bytes / 4, hipHostMallocDefault));
+      sl.pin_cap = bytes + bytes / 4;
+    }
+    memcpy(sl.pin, mel_btc, bytes);
+    src = sl.pin;
   }
-  // next carry: H frames of emitted context + everything not yet emitted
+  if (e->st_carry_n)
+    HIPCHK(e, hipMemcpy2DAsync(sl.win.p, row_win, e->st_carry.p, row_carry, row_carry, B, hipMemcpyDeviceToDevice, cp));
+  if (n)
+    HIPCHK(e, hipMemcpy2DAsync((char*)sl.win.p + row_carry, row_win, src, row_new, row_new, B, hipMemcpyDefault, cp));
+  int n_emit = emit_end - left_ctx;
+  if (n_emit < 0) n_emit = 0;
+  // next carry: H frames of emitted context + everything not yet emitted (it depends on the window alone, not on the pass)
   const int keep_from = std::max(0, (n_emit > 0 ? emit_end : left_ctx) - H);
   const int keep_n = last ? 0 : total - keep_from;
   if (keep_n > 0) {
     RET(ensure(e, e->st_carry, (size_t)B * keep_n * M * 4));
-    HIPCHK(e, hipMemcpy2DAsync(e->st_carry.p, (size_t)keep_n * M * 4, (char*)e->st_win.p + (size_t)keep_from * M * 4, row_win,
-                               (size_t)keep_n * M * 4, B, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(e, hipMemcpy2DAsync(e->st_carry.p, (size_t)keep_n * M * 4, (char*)sl.win.p + (size_t)keep_from * M * 4, row_win,
+                               (size_t)keep_n * M * 4, B, hipMemcpyDeviceToDevice, cp));
   }
   e->st_carry_n = keep_n;
   if (last) e->st_done = true;
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (n_emit > 0) {
+    HIPCHK(e, hipEventRecord(sl.win_ready, cp));
+    HIPCHK(e, hipStreamWaitEvent(sl.ctx.stream, sl.win_ready, 0));
+    hipStream_t const cs = sl.ctx.stream;
+    {
+      CtxSwap in_slot(e, sl.ctx);
+      RET(vocoder_impl(e, ptr<float>(sl.win), B, total, true, true, nullptr, nullptr, &sl.wav, &sl.pcm));
+    }
+    HIPCHK(e, hipEventRecord(sl.done, cs));
+    if (e->prof_on) HIPCHK(e, hipStreamSynchronize(cs));   // the profile's events are read after a wait on the engine's stream alone
+    sl.win_n = total;
+    sl.emit_off = left_ctx;
+    sl.emit_n = n_emit;
+    e->st_emitted += n_emit;
+    ++e->st_pending;
+  } else {
+    HIPCHK(e, hipStreamSynchronize(cp));   // nothing to fetch: this call is the only place its errors can surface
+  }
   if (n_frames_out) *n_frames_out = n_emit;
   return E2ETTS_OK;
 }
@@ -2063,15 +2178,19 @@ int e2etts_vocoder_stream_fetch(e2etts_engine* e, float* wav_out, int16_t* pcm_o
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(e, hipSetDevice(e->device));
-  if (!e->st_open || e->st_emit_n <= 0) return e->fail(E2ETTS_ESTATE, "the last push emitted nothing");
-  const size_t hop = e->cfg.hop_length, ns = (size_t)e->st_emit_n * hop;
+  if (!e->st_open || e->st_pending <= 0) return e->fail(E2ETTS_ESTATE, "no pushed chunk awaits a fetch (the last push emitted nothing?)");
+  auto& sl = e->st_slot[e->st_head];
+  const size_t hop = e->cfg.hop_length, ns = (size_t)sl.emit_n * hop;
   if (capacity < (size_t)e->st_B * ns) return e->fail(E2ETTS_EINVAL, "buffer holds %zu samples, chunk has %zu", capacity, (size_t)e->st_B * ns);
-  const size_t src_row = (size_t)e->st_win_n * hop, off = (size_t)e->st_emit_off * hop;
+  const size_t src_row = (size_t)sl.win_n * hop, off = (size_t)sl.emit_off * hop;
+  HIPCHK(e, hipStreamWaitEvent(e->stream, sl.done, 0));
   if (wav_out)
-    HIPCHK(e, hipMemcpy2DAsync(wav_out, ns * 4, ptr<float>(e->wav) + off, src_row * 4, ns * 4, e->st_B, hipMemcpyDefault, e->stream));
+    HIPCHK(e, hipMemcpy2DAsync(wav_out, ns * 4, ptr<float>(sl.wav) + off, src_row * 4, ns * 4, e->st_B, hipMemcpyDefault, e->stream));
   if (pcm_out)
-    HIPCHK(e, hipMemcpy2DAsync(pcm_out, ns * 2, ptr<int16_t>(e->pcm) + off, src_row * 2, ns * 2, e->st_B, hipMemcpyDefault, e->stream));
+    HIPCHK(e, hipMemcpy2DAsync(pcm_out, ns * 2, ptr<int16_t>(sl.pcm) + off, src_row * 2, ns * 2, e->st_B, hipMemcpyDefault, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->st_head ^= 1;
+  --e->st_pending;
   return E2ETTS_OK;
 }
 
@@ -2191,6 +2310,8 @@ int e2etts_sync(e2etts_engine* e) {
   std::lock_guard<std::mutex> lk(e->mu);
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (auto& sl : e->st_slot)
+    if (sl.ctx.stream) HIPCHK(e, hipStreamSynchronize(sl.ctx.stream));
   return E2ETTS_OK;
 }
 

@@ -191,8 +191,15 @@ E2ETTS_API int e2etts_fetch_wav(e2etts_engine* engine, float* wav_out, size_t ca
  * _begin, in frames; 15 for the default HiFi-GAN V1) and the not-yet-emittable tail internally, so HBM use is bounded by
  * the chunk size, and the concatenated output is bit-identical to one e2etts_vocoder call on the whole mel.
  *   _begin(B)                      -> halo in frames (>= 0) or a negative error
- *   _push(mel, n, last, &n_emit)   -> runs the vocoder on [context | pending | new]; n_emit frames became final
- *   _fetch(wav, pcm, capacity)     -> copies those n_emit * hop samples per utterance, [B, n_emit * hop] compact */
+ *   _push(mel, n, last, &n_emit)   -> enqueues the vocoder on [context | pending | new] and RETURNS; n_emit frames became final
+ *   _fetch(wav, pcm, capacity)     -> waits for the OLDEST unfetched push that emitted frames and copies its n_emit * hop samples per
+ *                                     utterance, [B, n_emit * hop] compact
+ * Up to two emitting pushes may await their fetch (a third fails with E2ETTS_ESTATE), so a caller either alternates push / fetch
+ * as before, or keeps the GPU busy across chunk boundaries: push(i + 1), then fetch(i) -- chunk i's samples travel to the host on a
+ * copy stream while chunk i + 1 computes.  Each in-flight chunk has its own output buffers; the resident one-shot result
+ * (e2etts_fetch_wav / _pcm) is not touched by the stream.  A chunk in pageable host memory has been consumed when _push returns; one in
+ * device memory, or in host memory the caller pinned, must stay valid until the fetch of that push (or e2etts_sync) returns.  Errors of
+ * the enqueued work surface at the fetch. */
 E2ETTS_API int e2etts_vocoder_stream_begin(e2etts_engine* engine, int B);
 E2ETTS_API int e2etts_vocoder_stream_push(e2etts_engine* engine, const float* mel_btc, int n_frames, int last, int* n_frames_out);
 E2ETTS_API int e2etts_vocoder_stream_fetch(e2etts_engine* engine, float* wav_out, int16_t* pcm_out, size_t capacity);

@@ -117,6 +117,72 @@ def test_streaming_equals_one_shot_bit_for_bit():
     np.testing.assert_array_equal(np.concatenate(pieces, axis=1), whole)
 
 
+def test_stream_keeps_two_chunks_in_flight():
+    """The C ABI's own orders (include/e2etts.h): push / fetch alternating as before round 4, and push(i + 1) before fetch(i); the
+    third unfetched push is refused; chunks in device memory; the resident one-shot result stays what it was."""
+    import ctypes as C
+    import torch
+    from e2e_tts_amd._lib import _addr
+    cfg = cfg48(64)
+    _, eng = make_engine(cfg, 32)
+    lib, h = eng.lib, eng._h
+    rng = np.random.Generator(np.random.PCG64(16))
+    T, hop = 200, 512
+    mel = rng.standard_normal((2, T, 80)).astype(np.float32)
+    eng.set_precision("bf16")
+    other = rng.standard_normal((1, 40, 80)).astype(np.float32)
+    other_wav, _ = eng.vocoder(other, 1, 40, channels_first=False)
+    whole, whole_pcm = eng.vocoder(mel, 2, T, channels_first=False, pcm=True)
+    chunks = [np.ascontiguousarray(mel[:, i:i + 48]) for i in range(0, T, 48)]
+
+    def push(c, last):
+        n_emit = C.c_int(0)
+        rc = lib.e2etts_vocoder_stream_push(h, _addr(c), int(c.shape[1]), int(last), C.byref(n_emit))
+        return rc, n_emit.value
+
+    def fetch(n_emit):
+        wav = np.empty((2, n_emit * hop), np.float32)
+        pcm = np.empty((2, n_emit * hop), np.int16)
+        assert lib.e2etts_vocoder_stream_fetch(h, _addr(wav), _addr(pcm), wav.size) == 0, lib.e2etts_last_error(h).decode()
+        return wav, pcm
+
+    # alternating
+    assert lib.e2etts_vocoder_stream_begin(h, 2) >= 0
+    got = []
+    for i, c in enumerate(chunks):
+        rc, n = push(c, i == len(chunks) - 1)
+        assert rc == 0 and n > 0
+        got.append(fetch(n))
+    np.testing.assert_array_equal(np.concatenate([g[0] for g in got], axis=1), whole)
+    np.testing.assert_array_equal(np.concatenate([g[1] for g in got], axis=1), whole_pcm)
+    assert lib.e2etts_vocoder_stream_fetch(h, _addr(np.empty((2, 1 << 20), np.float32)), None, 2 << 20) != 0   # nothing left
+
+    # two in flight, from device memory; the caller's buffers are overwritten as soon as pageable ones may be
+    assert lib.e2etts_vocoder_stream_begin(h, 2) >= 0
+    got, waiting = [], []
+    for i, c in enumerate(chunks):
+        src = torch.from_numpy(c).to(0) if i % 2 else c.copy()
+        rc, n = push(src, i == len(chunks) - 1)
+        assert rc == 0 and n > 0
+        if i % 2 == 0:
+            src[:] = 7.0   # pageable: consumed when push returned
+        waiting.append((n, src))
+        if len(waiting) == 2:
+            if i == 1:
+                rc3, _ = push(chunks[2], False)
+                assert rc3 != 0 and "await" in lib.e2etts_last_error(h).decode()
+            got.append(fetch(waiting.pop(0)[0]))
+    while waiting:
+        got.append(fetch(waiting.pop(0)[0]))
+    np.testing.assert_array_equal(np.concatenate([g[0] for g in got], axis=1), whole)
+    np.testing.assert_array_equal(np.concatenate([g[1] for g in got], axis=1), whole_pcm)
+    # the stream has its own output slots: the last one-shot result is still the resident one
+    res = np.empty_like(whole)
+    assert lib.e2etts_fetch_wav(h, _addr(res), res.size) == 0
+    np.testing.assert_array_equal(res, whole)
+    assert other_wav.shape == (1, 40 * hop)
+
+
 def test_long_form_60s_stream_bf16():
     """>= 60 s of 48 kHz audio (5 632 frames x 512) from one utterance, default-width generator, plain bf16, chunks of 512
     frames; checked against the one-shot run (bit-exact) and against the split-precision run (stated bf16 tolerance)."""

@@ -277,6 +277,9 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) for (int k = 0; k < 3; ++k) launch_pair_bf16(q[k], s);
     CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_old, e0, e1));
+#ifdef E2ETTS_BC_DIAG
+    { unsigned long long d[8]; conv_bf16_read_diag(d); }   // the pair launches' stamps: not this table's
+#endif
     CK(hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) launch_rb_bf16(r, s);
     CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_new, e0, e1));

@@ -818,7 +818,8 @@ def c5_longform(torch, traffic_json):
     eng = v.eval().to(0).engine
     mel = np.random.Generator(np.random.PCG64(7)).standard_normal((1, C5_FRAMES, 80)).astype(np.float32)
     rec = {"workload": f"48 kHz HiFi-GAN (8x8x4x2, hop 512, width 512), 1 utterance of {C5_FRAMES} frames = {C5_FRAMES * 512 / 48000:.2f} s, "
-                       f"streamed in chunks of {C5_CHUNK} frames, PCM fetched per chunk; mel resident on the host", "sample_rate": 48000}
+                       f"streamed in chunks of {C5_CHUNK} frames (two chunks in flight: push i + 1, then fetch i), PCM fetched per chunk; mel resident on the host",
+           "sample_rate": 48000}
 
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic_c5.json")) as fh:

@@ -18,6 +18,9 @@
 
 #include "../../include/e2etts.h"
 #include "host_logic.h"
+#ifndef E2ETTS_ST_DEPTH
+#define E2ETTS_ST_DEPTH 2   // chunks the streaming vocoder keeps in flight (tuning builds: 3)
+#endif
 #include "kernels.h"
 
 using namespace e2etts;
@@ -142,6 +145,7 @@ struct e2etts_engine {
   // one e2etts_order_after orders behind the caller's work).  That makes three streams busy at a time: a process has FOUR hardware
   // queues by default (GPU_MAX_HW_QUEUES), the null stream holds one, and streams beyond that share a queue, i.e. run in turn --
   // measured: with a copy stream of its own the two passes landed on one queue and did not overlap at all.
+  static constexpr int ST_DEPTH = E2ETTS_ST_DEPTH;
   struct VocCtx {   // what one vocoder pass works in besides the weights: swapped into the engine around vocoder_impl
     hipStream_t stream = nullptr;
     DevBuf v0, v1, v2, v3, vside[E2ETTS_MAX_RB_KERNELS - 1][3];
@@ -155,7 +159,7 @@ struct e2etts_engine {
     size_t pin_cap = 0;
     hipEvent_t done = nullptr, win_ready = nullptr;
     int emit_n = 0, emit_off = 0, win_n = 0;
-  } st_slot[2];
+  } st_slot[ST_DEPTH];
   int st_head = 0, st_pending = 0;
   int ragged = 1;         // synthesize(): skip rows of shorter utterances that no valid output sample depends on
   bool rag_short = false; // the last acoustic pass had an utterance shorter than T (else ragged mode has nothing to skip)
@@ -2112,11 +2116,11 @@ int e2etts_vocoder_stream_push(e2etts_engine* e, const float* mel_btc, int n, in
   HIPCHK(e, hipSetDevice(e->device));
   if (!e->st_open || e->st_done) return e->fail(E2ETTS_ESTATE, "no open vocoder stream");
   if (n < 0 || (n > 0 && !mel_btc)) return e->fail(E2ETTS_EINVAL, "bad chunk");
-  if (e->st_pending >= 2) return e->fail(E2ETTS_ESTATE, "two chunks await e2etts_vocoder_stream_fetch");
+  if (e->st_pending >= e2etts_engine::ST_DEPTH) return e->fail(E2ETTS_ESTATE, "%d chunks await e2etts_vocoder_stream_fetch", e2etts_engine::ST_DEPTH);
   const int B = e->st_B, H = e->st_halo, M = e->cfg.n_mel;
   const int total = e->st_carry_n + n;
   if (n_frames_out) *n_frames_out = 0;
-  auto& sl = e->st_slot[(e->st_head + e->st_pending) & 1];   // free: whatever used it last has been fetched, hence has finished
+  auto& sl = e->st_slot[(e->st_head + e->st_pending) % e2etts_engine::ST_DEPTH];   // free: whatever used it last has been fetched, hence has finished
   hipStream_t const cp = e->stream;   // assembly and copies: see the note at st_slot
   // window = [carry | new]; carry = up to H already-emitted frames (left context) followed by the frames not yet emitted
   const int left_ctx = (int)std::min<long long>(H, std::min<long long>(e->st_emitted, e->st_carry_n));
@@ -2156,9 +2160,15 @@ int e2etts_vocoder_stream_push(e2etts_engine* e, const float* mel_btc, int n, in
     HIPCHK(e, hipEventRecord(sl.win_ready, cp));
     HIPCHK(e, hipStreamWaitEvent(sl.ctx.stream, sl.win_ready, 0));
     hipStream_t const cs = sl.ctx.stream;
+    int rc;
     {
       CtxSwap in_slot(e, sl.ctx);
-      RET(vocoder_impl(e, ptr<float>(sl.win), B, total, true, true, nullptr, nullptr, &sl.wav, &sl.pcm));
+      rc = vocoder_impl(e, ptr<float>(sl.win), B, total, true, true, nullptr, nullptr, &sl.wav, &sl.pcm);
+    }
+    if (rc != E2ETTS_OK) {   // the carried context has moved on already: this stream cannot be continued
+      e->st_open = false;
+      (void)hipStreamSynchronize(cs);
+      return rc;
     }
     HIPCHK(e, hipEventRecord(sl.done, cs));
     if (e->prof_on) HIPCHK(e, hipStreamSynchronize(cs));   // the profile's events are read after a wait on the engine's stream alone
@@ -2189,7 +2199,7 @@ int e2etts_vocoder_stream_fetch(e2etts_engine* e, float* wav_out, int16_t* pcm_o
   if (pcm_out)
     HIPCHK(e, hipMemcpy2DAsync(pcm_out, ns * 2, ptr<int16_t>(sl.pcm) + off, src_row * 2, ns * 2, e->st_B, hipMemcpyDefault, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  e->st_head ^= 1;
+  e->st_head = (e->st_head + 1) % e2etts_engine::ST_DEPTH;
   --e->st_pending;
   return E2ETTS_OK;
 }
@@ -2261,6 +2271,21 @@ int e2etts_debug_poison_workspace(e2etts_engine* e) {
   for (auto& row : e->vside)
     for (DevBuf& b : row)
       if (b.p) HIPCHK(e, hipMemsetAsync(b.p, 0x4B, b.cap, e->stream));
+  // the stream slots' workspaces too (their outputs and windows only when nothing awaits a fetch)
+  for (auto& sl : e->st_slot) {
+    if (sl.ctx.stream) HIPCHK(e, hipStreamSynchronize(sl.ctx.stream));
+    DevBuf* ws[] = {&sl.ctx.v0, &sl.ctx.v1, &sl.ctx.v2, &sl.ctx.v3};
+    for (DevBuf* b : ws)
+      if (b->p) HIPCHK(e, hipMemsetAsync(b->p, 0x4B, b->cap, e->stream));
+    for (auto& row : sl.ctx.vside)
+      for (DevBuf& b : row)
+        if (b.p) HIPCHK(e, hipMemsetAsync(b.p, 0x4B, b.cap, e->stream));
+    if (e->st_pending == 0) {
+      DevBuf* outs[] = {&sl.wav, &sl.pcm, &sl.win};
+      for (DevBuf* b : outs)
+        if (b->p) HIPCHK(e, hipMemsetAsync(b->p, 0x4B, b->cap, e->stream));
+    }
+  }
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return E2ETTS_OK;
 }

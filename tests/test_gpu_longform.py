@@ -157,7 +157,11 @@ def test_stream_keeps_two_chunks_in_flight():
     np.testing.assert_array_equal(np.concatenate([g[1] for g in got], axis=1), whole_pcm)
     assert lib.e2etts_vocoder_stream_fetch(h, _addr(np.empty((2, 1 << 20), np.float32)), None, 2 << 20) != 0   # nothing left
 
-    # two in flight, from device memory; the caller's buffers are overwritten as soon as pageable ones may be
+    # two in flight, from device memory; the caller's buffers are overwritten as soon as pageable ones may be.  Nothing the slots'
+    # workspaces still hold from the first stream may matter
+    eng.poison_workspace()
+    again, _ = eng.vocoder(mel, 2, T, channels_first=False)
+    np.testing.assert_array_equal(again, whole)
     assert lib.e2etts_vocoder_stream_begin(h, 2) >= 0
     got, waiting = [], []
     for i, c in enumerate(chunks):

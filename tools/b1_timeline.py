@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """One step of a rocprofv3 kernel trace as a timeline: start [us since the step's first kernel], duration, stream, grid, kernel.
 
-    python3 tools/b1_timeline.py <kernel_trace.csv> [first kernel of a step = embed_kernel]
+    python3 tools/b1_timeline.py <kernel_trace.csv> [first kernel of a step = embed_kernel] [step, counted from the end = 1]
 
-Takes the LAST complete step in the trace (from one `embed_kernel` to the next).  A tuning aid for the B = 1 latency path, where the order
+Takes the LAST complete step in the trace (from one `embed_kernel` to the next), or the n-th from the end (the streaming vocoder keeps two
+chunks in flight: its last step is the drained pipeline, a step from the middle shows the overlap).  A tuning aid for the B = 1 latency path, where the order
 and overlap of ~190 short launches matter more than any one kernel's rate."""
 import csv
 import re
@@ -20,7 +21,10 @@ def main():
     starts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == first]
     if len(starts) < 2:
         raise SystemExit("need two steps in the trace")
-    a, b = starts[-2], starts[-1]
+    back = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    if len(starts) < back + 1:
+        raise SystemExit(f"the trace has {len(starts)} steps, step {back} from the end does not exist")
+    a, b = starts[-back - 1], starts[-back]
     t0 = int(rows[a]["Start_Timestamp"])
     streams = {}
     print("# start_us  dur_us  stream  threads  kernel")

@@ -17,7 +17,7 @@ for ch in $chunks; do
   echo "[profile_c5] chunk $ch timing done: $(head -1 "$out/time_$ch.txt")"
   rocprofv3 --kernel-trace --stats -d "$out/trace_$ch" --output-format csv -- python3 tools/longform_bench.py $ch $modes 2 > "$out/under_rocprof_$ch.txt" 2> "$out/trace_$ch.err"
   cp "$(find "$out/trace_$ch" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats_$ch.csv"
-  python3 tools/b1_timeline.py "$(find "$out/trace_$ch" -name '*kernel_trace.csv' | head -1)" "conv_post_kernel<256>" $([ "$ch" -le 1024 ] && echo 4 || echo 1) > "$out/timeline_$ch.txt"
+  python3 tools/b1_timeline.py "$(find "$out/trace_$ch" -name '*kernel_trace.csv' | head -1)" "conv_post_kernel<256>" $([ "$ch" -le 1024 ] && echo "4 2" || echo "1 1") > "$out/timeline_$ch.txt"
   rm -rf "$out/trace_$ch"
   echo "[profile_c5] chunk $ch kernel trace done"
   for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \

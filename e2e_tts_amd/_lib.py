@@ -448,6 +448,8 @@ class Engine:
             with self.lock:  # one step: push chunk i (returns once enqueued), then take chunk i - 1's samples while i computes.  The
                 # lock is NOT held across the yield below; the stream's context and its two output slots live in buffers of their own,
                 # so one-shot calls may run between steps
+                _expect(cur, "mel chunk", "float32", B * int(cur.shape[1]) * self.dims.n_mel)
+                self._order(cur)   # a chunk torch is still writing on its own stream: the copy into the window waits for it
                 self._check(self.lib.e2etts_vocoder_stream_push(self._h, _addr(cur), int(cur.shape[1]), 1 if nxt is None else 0,
                                                                 C.byref(n_emit)), "e2etts_vocoder_stream_push")
                 if n_emit.value > 0:

@@ -1799,6 +1799,16 @@ static int bind_resident_blob(e2etts_engine* e, size_t nbytes) {
   return E2ETTS_OK;
 }
 
+// New weights replace the tensors the stream slots' kernels read: whatever they still have in flight finishes first, and an open stream
+// is closed (its chunks were computed with the old weights; the next _push says so).
+static int drain_stream_slots(e2etts_engine* e) {
+  for (auto& sl : e->st_slot)
+    if (sl.ctx.stream) HIPCHK(e, hipStreamSynchronize(sl.ctx.stream));
+  e->st_open = false;
+  e->st_pending = 0;
+  return E2ETTS_OK;
+}
+
 int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
   if (!e) return E2ETTS_EINVAL;
   std::lock_guard<std::mutex> lk(e->mu);
@@ -1807,6 +1817,7 @@ int e2etts_load_weights(e2etts_engine* e, const void* blob, size_t nbytes) {
   BlobHeader h;
   HIPCHK(e, hipMemcpy(&h, blob, sizeof h, hipMemcpyDefault));
   if (const char* m = blob_check_header(h, nbytes)) return e->fail(E2ETTS_EINVAL, "%s", m);  // before anything resident is touched
+  RET(drain_stream_slots(e));
   e->ac_loaded = e->voc_loaded = false;
   RET(ensure(e, e->blob, nbytes));
   HIPCHK(e, hipMemcpyAsync(e->blob.p, blob, nbytes, hipMemcpyDefault, e->stream));
@@ -1862,6 +1873,7 @@ int e2etts_load_weights_bcast(e2etts_engine* e, const void* blob_or_null, size_t
   int rc = api.user_rank(rccl_comm, &rank);
   if (rc != 0) return e->fail(E2ETTS_EHIP, "ncclCommUserRank: %s", api.errstr ? api.errstr(rc) : "error");
   if (rank == root && !blob_or_null) return e->fail(E2ETTS_EINVAL, "the root rank must supply the blob");
+  RET(drain_stream_slots(e));
   e->ac_loaded = e->voc_loaded = false;
   RET(ensure(e, e->blob, nbytes));
   if (rank == root) HIPCHK(e, hipMemcpyAsync(e->blob.p, blob_or_null, nbytes, hipMemcpyDefault, e->stream));

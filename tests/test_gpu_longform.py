@@ -187,6 +187,33 @@ def test_stream_keeps_two_chunks_in_flight():
     assert other_wav.shape == (1, 40 * hop)
 
 
+def test_weight_reload_closes_an_open_stream():
+    """New weights while chunks are in flight: the slots' kernels finish first, the stream is closed, and a fresh stream gives the new
+    weights' result."""
+    import ctypes as C
+    from e2e_tts_amd.models import HifiGan
+    from e2e_tts_amd._lib import _addr
+    cfg = cfg48(64)
+    v = HifiGan(cfg["models"]["hifigan"])
+    v.load_state_dict(sw.to_torch(sw.make_vocoder_state(cfg, seed=41)))
+    eng = v.eval().to(0).engine
+    lib, h = eng.lib, eng._h
+    eng.set_precision("bf16")
+    rng = np.random.Generator(np.random.PCG64(17))
+    mel = rng.standard_normal((1, 96, 80)).astype(np.float32)
+    assert lib.e2etts_vocoder_stream_begin(h, 1) >= 0
+    n_emit = C.c_int(0)
+    assert lib.e2etts_vocoder_stream_push(h, _addr(mel[:, :48].copy()), 48, 0, C.byref(n_emit)) == 0 and n_emit.value > 0
+    v.load_state_dict(sw.to_torch(sw.make_vocoder_state(cfg, seed=42)))   # repacks and reloads into the same engine
+    assert v.engine is eng
+    rc = lib.e2etts_vocoder_stream_push(h, _addr(mel[:, 48:].copy()), 48, 1, C.byref(n_emit))
+    assert rc != 0 and "no open vocoder stream" in lib.e2etts_last_error(h).decode()
+    eng.set_precision("bf16")
+    whole, _ = eng.vocoder(mel, 1, 96, channels_first=False)
+    out = np.concatenate(list(eng.vocoder_stream([mel[:, :48].copy(), mel[:, 48:].copy()], 1)), axis=1)
+    np.testing.assert_array_equal(out, whole)
+
+
 def test_long_form_60s_stream_bf16():
     """>= 60 s of 48 kHz audio (5 632 frames x 512) from one utterance, default-width generator, plain bf16, chunks of 512
     frames; checked against the one-shot run (bit-exact) and against the split-precision run (stated bf16 tolerance)."""

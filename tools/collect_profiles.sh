@@ -29,5 +29,9 @@ if [ -d "$src/c5" ]; then
     python3 tools/pmc_summary.py "$src/c5/pmc_$ch" "$dst" --name pmc_c5_$ch.md $extra --cmd "python3 tools/longform_bench.py $ch bf16 1" \
       --title "Round ${2#r}, BASELINE config 5 (48 kHz HiFi-GAN, 60.07 s, plain bf16), mel pushed in chunks of $ch frames"
   done
+  # the name VERDICT r3 asked for: the chunk-512 table (the configuration the bench line quotes), with a pointer to the one-call table
+  if [ -f "$dst/pmc_c5_512.md" ]; then
+    { cat "$dst/pmc_c5_512.md"; echo; echo "(One call on the whole utterance: \`pmc_c5_5632.md\`.  Round 3's kernels under the same passes: \`pmc_c5_512_round3_build.md\`.)"; } > "$dst/pmc_c5.md"
+  fi
 fi
 ls -la "$dst"
